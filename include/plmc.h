@@ -1,0 +1,138 @@
+/*
+ * plmc.h -- C ABI of the MI355X-native exact-GP hot path behind the projectedlmc model API.
+ *
+ * The reference (QWERTY6191/projected-lmc) has no FFI: its hot path is reached through
+ * gpytorch calls made by its Python classes.  Each entry point below replaces the named
+ * reference call site (file:line in /root/reference/projectedlmc/projected_lmc.py unless
+ * stated) and the third-party kernels that call site triggers.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  All pointers are DEVICE pointers
+ *     owned by the caller (workspace included); the library allocates nothing and keeps no
+ *     pointer after return.  Every call is asynchronous on `stream` (a hipStream_t passed as
+ *     void*).  Return value: 0 = launched, <0 = argument / HIP error (see plmc_last_error()).
+ *   - dtype by suffix: _f32 / _f64.  Everything row-major.
+ *   - Blocked algorithms use NB = 128 (plmc_block()).  n_pad = plmc_pad(n) = n rounded up to NB.
+ *   - "Factor buffer" A, one per latent GP (batch stride strideA elements):
+ *        n_pad rows x lda columns, lda = n_pad + naug_pad (naug_pad = plmc_pad(naug), >= 0).
+ *        columns [0, n_pad)       : UPPER triangle holds Khat = K + noise*I, then its factor U
+ *                                   (Khat = U^T U); padded rows/cols hold the identity.
+ *        columns [n_pad, lda)     : augmented right-hand sides (targets, cross-covariances);
+ *                                   potrf turns each column c into U^-T c (forward solve for free).
+ *     The strictly lower triangle of the square part is never read.
+ *   - Vd: per latent (n_pad/NB) blocks of NB x NB: inverses of the diagonal blocks of U (upper).
+ *   - W : per latent n_pad x ldw (ldw >= n_pad), LOWER triangle = U^-T (explicit zeros above the
+ *         diagonal inside diagonal blocks; blocks strictly above the diagonal are never touched).
+ *   - kernel kinds: PLMC_RBF, PLMC_MATERN12, PLMC_MATERN32, PLMC_MATERN52.
+ */
+#ifndef PLMC_H
+#define PLMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PLMC_RBF = 0, PLMC_MATERN12 = 1, PLMC_MATERN32 = 2, PLMC_MATERN52 = 3 };
+
+/* Library identification / geometry. */
+int         plmc_version(void);
+int         plmc_block(void);                 /* NB (128) */
+int64_t     plmc_pad(int64_t n);              /* n rounded up to a multiple of NB */
+int         plmc_max_dim(void);               /* largest input dimension d accepted by the fused kernels */
+const char *plmc_last_error(void);            /* text of the last error on the calling thread */
+/* Bytes of the `partials` scratch plmc_kinv_grad_* needs for (n_pad, q). */
+int64_t     plmc_grad_scratch_bytes(int64_t n_pad, int q);
+
+/*
+ * Covariance assembly.  Replaces `self.covar_module(x)` (:316, :1090; kernels built by
+ * handle_covar_ :151-167) fused with `likelihood(dist)` = +noise*I (:1200):
+ *   A[i][j] = oscale * k(|x_i - x_j| / ell) + noise * (i==j)   for i <= j < n  (upper tiles)
+ * X: n x d, ell: q x d, oscale: q or NULL, noise: q.
+ */
+int plmc_assemble_f32(int kind, const float *X, int n, int d, const float *ell, const float *oscale,
+                      const float *noise, float *A, int64_t lda, int64_t strideA, int q, void *stream);
+int plmc_assemble_f64(int kind, const double *X, int n, int d, const double *ell, const double *oscale,
+                      const double *noise, double *A, int64_t lda, int64_t strideA, int q, void *stream);
+
+/*
+ * Write right-hand sides into the augmented block: A[i][n_pad + c0 + r] = rhs[latent][r][i]
+ * (rhs: q x nrhs x n, e.g. the projected targets of project_data :1014-1021, which are q x n).
+ * Rows >= n and the columns of the augmented block not covered by any write are zeroed when
+ * `zero_fill` != 0 (columns [n_pad, lda) are cleared before writing).
+ */
+int plmc_write_rhs_f32(const float *rhs, int nrhs, int n, float *A, int64_t lda, int64_t strideA,
+                       int c0, int zero_fill, int q, void *stream);
+int plmc_write_rhs_f64(const double *rhs, int nrhs, int n, double *A, int64_t lda, int64_t strideA,
+                       int c0, int zero_fill, int q, void *stream);
+
+/*
+ * Cross-covariance block (prediction, ProjectedGPModel.__call__ eval branch :1133-1134 -> gpytorch
+ * prediction strategy):  Out[i][col0 + j] = oscale * k(x_i, xs_j)  for i < n, j < ns; rows
+ * n <= i < n_rows are zero-filled.  To fill the augmented block of a factor buffer pass Out = A,
+ * ldo = lda, col0 = n_pad + c0, n_rows = n_pad; any other dense (n_rows x ldo) buffer works too.
+ */
+int plmc_assemble_cross_f32(int kind, const float *X, int n, const float *Xs, int ns, int d,
+                            const float *ell, const float *oscale, float *Out, int64_t ldo,
+                            int64_t strideO, int64_t col0, int64_t n_rows, int q, void *stream);
+int plmc_assemble_cross_f64(int kind, const double *X, int n, const double *Xs, int ns, int d,
+                            const double *ell, const double *oscale, double *Out, int64_t ldo,
+                            int64_t strideO, int64_t col0, int64_t n_rows, int q, void *stream);
+
+/*
+ * Blocked right-looking Cholesky of the augmented buffer, Khat = U^T U, in place.
+ * Replaces torch.linalg.cholesky_ex + the forward triangular solve behind
+ * `latent_output.log_prob(proj_target)` (:1201) / ExactMarginalLogLikelihood (experiments.py:233).
+ *   logdet[latent] = log det Khat   (double), info[latent] = 0 or 1 + index of first non-PD pivot.
+ * naug = number of live augmented columns (0 allowed).
+ */
+int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd,
+                   double *logdet, int *info, int q, void *stream);
+int plmc_potrf_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, double *Vd,
+                   double *logdet, int *info, int q, void *stream);
+
+/*
+ * Gather augmented column c of every latent into a contiguous vector z (q x n_pad) and return
+ * quad[latent] = sum z^2 in double (the inv_quad term of MVN.log_prob, :1201).
+ */
+int plmc_extract_col_f32(const float *A, int64_t n_pad, int64_t lda, int64_t strideA, int c,
+                         float *z, double *quad, int q, void *stream);
+int plmc_extract_col_f64(const double *A, int64_t n_pad, int64_t lda, int64_t strideA, int c,
+                         double *z, double *quad, int q, void *stream);
+
+/* W = U^-T (lower), blocked forward substitution on MFMA.  First third of the K^-1 needed by
+ * `loss.backward()` (experiments.py:270). */
+int plmc_trtri_f32(const float *A, int64_t n_pad, int64_t lda, int64_t strideA, const float *Vd,
+                   float *W, int64_t ldw, int64_t strideW, int q, void *stream);
+int plmc_trtri_f64(const double *A, int64_t n_pad, int64_t lda, int64_t strideA, const double *Vd,
+                   double *W, int64_t ldw, int64_t strideW, int q, void *stream);
+
+/* alpha = W^T z = Khat^-1 y  (q x n_pad).  d logp / d y = -alpha. */
+int plmc_wt_matvec_f32(const float *W, int64_t n_pad, int64_t ldw, int64_t strideW, const float *z,
+                       float *alpha, int q, void *stream);
+int plmc_wt_matvec_f64(const double *W, int64_t n_pad, int64_t ldw, int64_t strideW, const double *z,
+                       double *alpha, int q, void *stream);
+
+/*
+ * Fused K^-1 = W^T W (MFMA) + analytic MLL gradient reduction: for every upper tile of K^-1 the
+ * epilogue forms (alpha alpha^T - K^-1) o dKhat/dtheta from X staged in LDS and reduces it.
+ *   grad[latent][0..d-1] = d logp / d ell_k,  [d] = d/d noise,  [d+1] = d/d oscale   (double)
+ * Optional outputs (may be NULL): Kinv (n_pad x ldk upper tiles, batch stride strideK),
+ * kinv_diag (q x n_pad: diagonal of K^-1, for leave-one-out, compute_loo :1108-1119).
+ * partials: scratch of plmc_grad_scratch_bytes(n_pad, q) bytes.
+ */
+int plmc_kinv_grad_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW,
+                       const float *alpha, const float *X, int n, int d, const float *ell,
+                       const float *oscale, double *grad, float *Kinv, int64_t ldk, int64_t strideK,
+                       float *kinv_diag, void *partials, int q, void *stream);
+int plmc_kinv_grad_f64(int kind, const double *W, int64_t n_pad, int64_t ldw, int64_t strideW,
+                       const double *alpha, const double *X, int n, int d, const double *ell,
+                       const double *oscale, double *grad, double *Kinv, int64_t ldk, int64_t strideK,
+                       double *kinv_diag, void *partials, int q, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLMC_H */

@@ -1,0 +1,186 @@
+// assemble.hip -- fused covariance assembly X -> Khat (upper tiles), right-hand sides and
+// cross-covariances into the augmented block.  HBM-write bound: one pass, X staged in LDS.
+//
+// Replaces `self.covar_module(x)` + `likelihood(dist)` of the reference
+// (projected_lmc.py:316,1090,1200; kernels from handle_covar_ :151-167), i.e. the ~8 unfused
+// ATen launches and q*n*n temporaries gpytorch makes per kernel evaluation.
+#include "api_common.hpp"
+#include "covariance.hpp"
+#include "../../include/plmc.h"
+
+namespace plmc {
+
+// grid (m, m, q): blockIdx.x = column block jb, blockIdx.y = row block ib; tiles with jb < ib exit.
+// Each thread produces 8 rows x 2 groups of 4 consecutive columns (16-byte stores for f32).
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_assemble(int kind, const T *__restrict__ X, int n, int d,
+                                                        const T *__restrict__ ell, const T *__restrict__ oscale,
+                                                        const T *__restrict__ noise, T *__restrict__ A,
+                                                        int64_t lda, int64_t strideA) {
+  const int jb = blockIdx.x, ib = blockIdx.y, lat = blockIdx.z;
+  if (jb < ib) return;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T *ui = reinterpret_cast<T *>(smem_raw);
+  const int ldu = d + 1;
+  T *uj = ui + NB * ldu;
+  const int tid = threadIdx.x;
+  const T *el = ell + (int64_t)lat * d;
+  for (int e = tid; e < NB * d; e += NTHREADS) {
+    int r = e / d, k = e % d;
+    int gi = ib * NB + r, gj = jb * NB + r;
+    T inv = T(1) / el[k];
+    ui[r * ldu + k] = gi < n ? X[(int64_t)gi * d + k] * inv : T(0);
+    uj[r * ldu + k] = gj < n ? X[(int64_t)gj * d + k] * inv : T(0);
+  }
+  __syncthreads();
+  const T os = oscale ? oscale[lat] : T(1);
+  const T nz = noise[lat];
+  T *Al = A + (int64_t)lat * strideA;
+  const int tx = tid & 15, ty = tid >> 4;
+#pragma unroll 1
+  for (int rr = 0; rr < 8; ++rr) {
+    const int r = ty + 16 * rr;
+    const int gi = ib * NB + r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c0 = tx * 4 + 64 * h;
+      T v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int gj = jb * NB + c0 + c;
+        T r2 = T(0);
+        for (int k = 0; k < d; ++k) {
+          T df = ui[r * ldu + k] - uj[(c0 + c) * ldu + k];
+          r2 += df * df;
+        }
+        T val;
+        if (gi < n && gj < n) {
+          val = os * kern_value<T>(kind, r2);
+          if (gi == gj) val += nz;
+        } else {
+          val = (gi == gj) ? T(1) : T(0);       // identity padding keeps the padded factor trivial
+        }
+        v[c] = val;
+      }
+      T *dst = Al + (int64_t)gi * lda + jb * NB + c0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dst[c] = v[c];
+    }
+  }
+}
+
+// One thread per element of the augmented block (n_pad x naug_pad).
+template <typename T>
+__global__ void k_write_rhs(const T *__restrict__ rhs, int nrhs, int n, T *__restrict__ A, int64_t n_pad,
+                            int64_t lda, int64_t strideA, int c0, int zero_fill) {
+  const int lat = blockIdx.y;
+  const int64_t naug_pad = lda - n_pad;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_pad * naug_pad) return;
+  const int64_t i = idx / naug_pad;
+  const int c = (int)(idx % naug_pad);
+  T *p = A + (int64_t)lat * strideA + i * lda + n_pad + c;
+  if (c >= c0 && c < c0 + nrhs) {
+    *p = i < n ? rhs[((int64_t)lat * nrhs + (c - c0)) * n + i] : T(0);
+  } else if (zero_fill) {
+    *p = T(0);
+  }
+}
+
+// Out[i][col0 + j] = os * k(x_i, xs_j); block = 64 (j) x 4 (i).
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_assemble_cross(int kind, const T *__restrict__ X, int n,
+                                                              const T *__restrict__ Xs, int ns, int d,
+                                                              const T *__restrict__ ell, const T *__restrict__ oscale,
+                                                              T *__restrict__ A, int64_t n_rows, int64_t lda,
+                                                              int64_t strideA, int64_t col0) {
+  const int lat = blockIdx.z;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t i = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (j >= ns || i >= n_rows) return;
+  const T *el = ell + (int64_t)lat * d;
+  T val = T(0);
+  if (i < n) {
+    T r2 = T(0);
+    for (int k = 0; k < d; ++k) {
+      T df = (X[i * d + k] - Xs[(int64_t)j * d + k]) / el[k];
+      r2 += df * df;
+    }
+    val = (oscale ? oscale[lat] : T(1)) * kern_value<T>(kind, r2);
+  }
+  A[(int64_t)lat * strideA + i * lda + col0 + j] = val;
+}
+
+template <typename T>
+int assemble_impl(int kind, const T *X, int n, int d, const T *ell, const T *oscale, const T *noise, T *A,
+                  int64_t lda, int64_t strideA, int q, void *stream) {
+  PLMC_REQUIRE(kind >= 0 && kind <= 3, "unknown kernel kind");
+  PLMC_REQUIRE(X && ell && noise && A, "null pointer");
+  PLMC_REQUIRE(n > 0 && q > 0 && d > 0 && d <= MAX_DIM, "need n>0, q>0, 0<d<=plmc_max_dim()");
+  const int64_t n_pad = plmc_pad(n);
+  PLMC_REQUIRE(lda >= n_pad && lda % NB == 0, "lda must be a multiple of NB and >= n_pad");
+  PLMC_REQUIRE(strideA >= n_pad * lda || q == 1, "strideA too small");
+  const int m = (int)(n_pad / NB);
+  size_t smem = 2 * NB * (d + 1) * sizeof(T);
+  hipLaunchKernelGGL(k_assemble<T>, dim3(m, m, q), dim3(NTHREADS), smem, (hipStream_t)stream, kind, X, n, d, ell,
+                     oscale, noise, A, lda, strideA);
+  return launch_status(__func__);
+}
+
+template <typename T>
+int write_rhs_impl(const T *rhs, int nrhs, int n, T *A, int64_t lda, int64_t strideA, int c0, int zero_fill, int q,
+                   void *stream) {
+  PLMC_REQUIRE(A && (rhs || nrhs == 0), "null pointer");
+  const int64_t n_pad = plmc_pad(n);
+  PLMC_REQUIRE(lda > n_pad && lda % NB == 0, "no augmented block (lda must exceed n_pad)");
+  PLMC_REQUIRE(c0 >= 0 && nrhs >= 0 && n_pad + c0 + nrhs <= lda, "rhs columns exceed the augmented block");
+  const int64_t tot = n_pad * (lda - n_pad);
+  hipLaunchKernelGGL(k_write_rhs<T>, dim3((unsigned)((tot + 255) / 256), q), dim3(256), 0, (hipStream_t)stream, rhs,
+                     nrhs, n, A, n_pad, lda, strideA, c0, zero_fill);
+  return launch_status(__func__);
+}
+
+template <typename T>
+int assemble_cross_impl(int kind, const T *X, int n, const T *Xs, int ns, int d, const T *ell, const T *oscale, T *Out,
+                        int64_t ldo, int64_t strideO, int64_t col0, int64_t n_rows, int q, void *stream) {
+  PLMC_REQUIRE(kind >= 0 && kind <= 3, "unknown kernel kind");
+  PLMC_REQUIRE(X && Xs && ell && Out, "null pointer");
+  PLMC_REQUIRE(n > 0 && ns > 0 && q > 0 && d > 0 && d <= MAX_DIM, "bad sizes");
+  PLMC_REQUIRE(n_rows >= n && col0 >= 0 && col0 + ns <= ldo, "cross block exceeds the output buffer");
+  hipLaunchKernelGGL(k_assemble_cross<T>, dim3((ns + 63) / 64, (unsigned)((n_rows + 3) / 4), q), dim3(NTHREADS), 0,
+                     (hipStream_t)stream, kind, X, n, Xs, ns, d, ell, oscale, Out, n_rows, ldo, strideO, col0);
+  return launch_status(__func__);
+}
+
+}  // namespace plmc
+
+extern "C" {
+int plmc_assemble_f32(int kind, const float *X, int n, int d, const float *ell, const float *oscale,
+                      const float *noise, float *A, int64_t lda, int64_t strideA, int q, void *stream) {
+  return plmc::assemble_impl<float>(kind, X, n, d, ell, oscale, noise, A, lda, strideA, q, stream);
+}
+int plmc_assemble_f64(int kind, const double *X, int n, int d, const double *ell, const double *oscale,
+                      const double *noise, double *A, int64_t lda, int64_t strideA, int q, void *stream) {
+  return plmc::assemble_impl<double>(kind, X, n, d, ell, oscale, noise, A, lda, strideA, q, stream);
+}
+int plmc_write_rhs_f32(const float *rhs, int nrhs, int n, float *A, int64_t lda, int64_t strideA, int c0,
+                       int zero_fill, int q, void *stream) {
+  return plmc::write_rhs_impl<float>(rhs, nrhs, n, A, lda, strideA, c0, zero_fill, q, stream);
+}
+int plmc_write_rhs_f64(const double *rhs, int nrhs, int n, double *A, int64_t lda, int64_t strideA, int c0,
+                       int zero_fill, int q, void *stream) {
+  return plmc::write_rhs_impl<double>(rhs, nrhs, n, A, lda, strideA, c0, zero_fill, q, stream);
+}
+int plmc_assemble_cross_f32(int kind, const float *X, int n, const float *Xs, int ns, int d, const float *ell,
+                            const float *oscale, float *Out, int64_t ldo, int64_t strideO, int64_t col0,
+                            int64_t n_rows, int q, void *stream) {
+  return plmc::assemble_cross_impl<float>(kind, X, n, Xs, ns, d, ell, oscale, Out, ldo, strideO, col0, n_rows, q,
+                                          stream);
+}
+int plmc_assemble_cross_f64(int kind, const double *X, int n, const double *Xs, int ns, int d, const double *ell,
+                            const double *oscale, double *Out, int64_t ldo, int64_t strideO, int64_t col0,
+                            int64_t n_rows, int q, void *stream) {
+  return plmc::assemble_cross_impl<double>(kind, X, n, Xs, ns, d, ell, oscale, Out, ldo, strideO, col0, n_rows, q,
+                                           stream);
+}
+}

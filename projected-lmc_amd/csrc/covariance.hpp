@@ -1,0 +1,44 @@
+// covariance.hpp -- stationary ARD kernel profiles shared by assembly and gradient kernels.
+// Restates the kernels handle_covar_ builds (projected_lmc.py:151-167): gpytorch RBFKernel and
+// MaternKernel(nu in {1/2,3/2,5/2}) on scaled inputs u = x / ell  [gpytorch-knowledge].
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace plmc {
+
+enum { K_RBF = 0, K_MATERN12 = 1, K_MATERN32 = 2, K_MATERN52 = 3 };
+
+__device__ __forceinline__ float  dexp(float x) { return expf(x); }
+__device__ __forceinline__ double dexp(double x) { return exp(x); }
+__device__ __forceinline__ float  dsqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double dsqrt(double x) { return sqrt(x); }
+
+// k(r2) for unit output scale, r2 = |u - u'|^2.
+template <typename T> __device__ __forceinline__ T kern_value(int kind, T r2) {
+  if (kind == K_RBF) return dexp(T(-0.5) * r2);
+  T r = dsqrt(r2 > T(0) ? r2 : T(0));
+  if (kind == K_MATERN12) return dexp(-r);
+  if (kind == K_MATERN32) { T s = T(1.7320508075688772) * r; return (T(1) + s) * dexp(-s); }
+  T s = T(2.23606797749979) * r;
+  return (T(1) + s + T(5.0 / 3.0) * r2) * dexp(-s);
+}
+
+// value and "base" such that  d k / d ell_k = base * (u_k - u'_k)^2 / ell_k   (unit output scale).
+template <typename T> __device__ __forceinline__ void kern_value_base(int kind, T r2, T &val, T &base) {
+  if (kind == K_RBF) { val = dexp(T(-0.5) * r2); base = val; return; }
+  T r = dsqrt(r2 > T(0) ? r2 : T(0));
+  if (kind == K_MATERN12) {
+    val = dexp(-r);
+    base = r > T(1e-15) ? val / r : T(0);
+    return;
+  }
+  if (kind == K_MATERN32) {
+    T s = T(1.7320508075688772) * r, e = dexp(-s);
+    val = (T(1) + s) * e; base = T(3) * e; return;
+  }
+  T s = T(2.23606797749979) * r, e = dexp(-s);
+  val = (T(1) + s + T(5.0 / 3.0) * r2) * e;
+  base = T(5.0 / 3.0) * (T(1) + s) * e;
+}
+
+}  // namespace plmc

@@ -1,0 +1,171 @@
+// gemm_core.hpp -- the one MFMA tile engine every blocked routine is built from (gfx950 only).
+//
+// All dense work on the hot path is expressed as "TN" products  C[i][j] (+)= sum_k A[k][i] * B[k][j]
+// where BOTH operands are stored K-major (row index = contraction index).  That is what the
+// HBM layout was chosen for: Khat = U^T U with U upper / row-major makes the Cholesky trailing
+// update, the panel solve, the forward substitution W = U^-T and K^-1 = W^T W all TN products,
+// so tiles stream from global to LDS without a transpose and MFMA fragments are read
+// conflict-free (LDS row stride 144 == 16 mod 32 words).
+//
+// Workgroup = 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 =
+// 4 x 4 MFMA tiles of v_mfma_{f32,f64}_16x16x4 (the f32 form runs at the f32 matrix peak,
+// 64 FLOP/clk/SIMD; MI355X_MICROARCH.md "Matrix cores").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace plmc {
+
+constexpr int NB = 128;    // block edge of all blocked algorithms == tile edge
+constexpr int BK = 16;     // k-depth of one LDS stage
+constexpr int LDT = 144;   // LDS row stride in elements
+constexpr int NTHREADS = 256;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Traits;
+template <> struct Traits<float> {
+  using acc_t = f32x4;
+  using vec_t = f32x4;                 // 16-byte global/LDS vector
+  static constexpr int EPV = 4;        // elements per 16 B
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = (lane >> 4) * 4 + reg
+  static __device__ __forceinline__ int acc_row(int lane, int r) { return ((lane >> 4) << 2) + r; }
+};
+template <> struct Traits<double> {
+  using acc_t = f64x4;
+  using vec_t = f64x2;
+  static constexpr int EPV = 2;
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  static __device__ __forceinline__ int acc_row(int lane, int r) { return (lane >> 4) + (r << 2); }
+};
+
+template <typename T> struct Acc {
+  typename Traits<T>::acc_t v[4][4];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[a][b][r] = T(0);
+  }
+};
+
+// LDS needed by tile_mainloop: 2 stages x (A,B) x BK x LDT elements.
+template <typename T> constexpr int tile_smem_elems() { return 2 * 2 * BK * LDT; }
+
+// Position of accumulator element (mt, nt, r) of this lane inside the 128x128 block tile.
+template <typename T> __device__ __forceinline__ int tile_row(int wm, int mt, int lane, int r) {
+  return wm * 64 + mt * 16 + Traits<T>::acc_row(lane, r);
+}
+__device__ __forceinline__ int tile_col(int wn, int nt, int lane) { return wn * 64 + nt * 16 + (lane & 15); }
+
+// acc += (negate ? -1 : 1) * sum_{k < K} Ag[k][0..127]^T * Bg[k][0..127]
+// Ag/Bg point at the first row of the K range and the first of the 128 columns; K % BK == 0.
+// All 256 threads must call it; ends with a barrier (LDS free for reuse on return).
+template <typename T, bool NEG>
+__device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__ Ag, int64_t lda,
+                                              const T *__restrict__ Bg, int64_t ldb, int K, T *smem) {
+  using Tr = Traits<T>;
+  using vec_t = typename Tr::vec_t;
+  constexpr int EPV = Tr::EPV;
+  constexpr int CPR = 128 / EPV;                     // 16-byte chunks per tile row
+  constexpr int NCH = BK * CPR / NTHREADS;           // chunks per thread per operand (2 / 4)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  T *sA = smem;
+  T *sB = smem + 2 * BK * LDT;
+
+  vec_t ra[NCH], rb[NCH];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      int c = tid + h * NTHREADS;
+      int row = c / CPR, col = (c % CPR) * EPV;
+      ra[h] = *reinterpret_cast<const vec_t *>(Ag + (int64_t)(kt * BK + row) * lda + col);
+      rb[h] = *reinterpret_cast<const vec_t *>(Bg + (int64_t)(kt * BK + row) * ldb + col);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      int c = tid + h * NTHREADS;
+      int row = c / CPR, col = (c % CPR) * EPV;
+      *reinterpret_cast<vec_t *>(sA + (buf * BK + row) * LDT + col) = ra[h];
+      *reinterpret_cast<vec_t *>(sB + (buf * BK + row) * LDT + col) = rb[h];
+    }
+  };
+
+  const int nkt = K / BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  const int fk = lane >> 4, fm = lane & 15;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) gload(kt + 1);
+    const T *pa = sA + buf * BK * LDT + wm * 64 + fm;
+    const T *pb = sB + buf * BK * LDT + wn * 64 + fm;
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      T a[4], b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[t] = pa[(ks * 4 + fk) * LDT + t * 16];
+        b[t] = pb[(ks * 4 + fk) * LDT + t * 16];
+        if (NEG) a[t] = -a[t];
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc.v[mt][nt] = Tr::mfma(a[mt], b[nt], acc.v[mt][nt]);
+    }
+    if (kt + 1 < nkt) sstore(buf ^ 1);
+    __syncthreads();
+  }
+}
+
+// C[tile] = acc (plain store of the 128x128 tile at Cg, leading dimension ldc).
+template <typename T>
+__device__ __forceinline__ void tile_store(const Acc<T> &acc, T *Cg, int64_t ldc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = tile_row<T>(wm, mt, lane, r);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) Cg[(int64_t)row * ldc + tile_col(wn, nt, lane)] = acc.v[mt][nt][r];
+    }
+}
+
+// C[tile] += acc  (used with NEG mainloop for C -= A^T B).
+template <typename T>
+__device__ __forceinline__ void tile_add_store(const Acc<T> &acc, T *Cg, int64_t ldc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = tile_row<T>(wm, mt, lane, r);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        T *p = Cg + (int64_t)row * ldc + tile_col(wn, nt, lane);
+        *p = *p + acc.v[mt][nt][r];
+      }
+    }
+}
+
+}  // namespace plmc

@@ -1,0 +1,210 @@
+// potri_grad.hip -- K^-1 = W^T W on MFMA with the analytic MLL gradient fused into the epilogue.
+//
+// Replaces the autograd backward of cholesky + kernel chain that `loss.backward()`
+// (experiments.py:270) runs through gpytorch:
+//     d logp / d theta = 1/2 tr((alpha alpha^T - Khat^-1) dKhat/dtheta),   d logp / d y = -alpha.
+// For each upper tile (ib <= jb) of K^-1 the workgroup accumulates the tile on MFMA, then,
+// without writing it to HBM, re-derives dK/dtheta for the same (i,j) from X staged in LDS and
+// reduces (alpha_i alpha_j - Kinv_ij) * dK_ij to d+2 partial sums.  A second tiny kernel sums the
+// per-tile partials in a fixed order (deterministic, no float atomics).
+#include "api_common.hpp"
+#include "covariance.hpp"
+#include "../../include/plmc.h"
+
+namespace plmc {
+
+constexpr int GP = MAX_DIM + 2;      // partial-sum slots per tile: d lengthscales, noise, outputscale
+
+template <typename T, int DCAP>
+__global__ __launch_bounds__(NTHREADS) void k_kinv_grad(int kind, const T *__restrict__ W, int64_t n_pad, int64_t ldw,
+                                                         int64_t strideW, const T *__restrict__ alpha,
+                                                         const T *__restrict__ X, int n, int d,
+                                                         const T *__restrict__ ell, const T *__restrict__ oscale,
+                                                         T *Kinv, int64_t ldk, int64_t strideK, T *kinv_diag,
+                                                         double *__restrict__ partials) {
+  const int jb = blockIdx.x, ib = blockIdx.y, lat = blockIdx.z;
+  if (jb < ib) return;
+  __shared__ __align__(16) T smem[tile_smem_elems<T>()];
+  const int m = (int)(n_pad / NB);
+  const T *Wl = W + (int64_t)lat * strideW + (int64_t)jb * NB * ldw;
+  Acc<T> acc;
+  acc.zero();
+  tile_mainloop<T, false>(acc, Wl + (int64_t)ib * NB, ldw, Wl + (int64_t)jb * NB, ldw, (int)(n_pad - (int64_t)jb * NB),
+                          smem);
+
+  // ---- epilogue: stage scaled inputs u = x / ell and alpha for the tile's rows and columns
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ldu = d + 1;
+  T *ui = smem;                        // [128][ldu]
+  T *uj = ui + NB * ldu;               // [128][ldu]
+  T *ai = uj + NB * ldu;               // [128]
+  T *aj = ai + NB;                     // [128]
+  const T *el = ell + (int64_t)lat * d;
+  for (int e = tid; e < NB * d; e += NTHREADS) {
+    int r = e / d, k = e % d;
+    int gi = ib * NB + r, gj = jb * NB + r;
+    T inv = T(1) / el[k];
+    ui[r * ldu + k] = gi < n ? X[(int64_t)gi * d + k] * inv : T(0);
+    uj[r * ldu + k] = gj < n ? X[(int64_t)gj * d + k] * inv : T(0);
+  }
+  if (tid < NB) {
+    ai[tid] = alpha[(int64_t)lat * n_pad + ib * NB + tid];
+    aj[tid] = alpha[(int64_t)lat * n_pad + jb * NB + tid];
+  }
+  __syncthreads();
+
+  const T os = oscale ? oscale[lat] : T(1);
+  double g[DCAP];
+#pragma unroll
+  for (int k = 0; k < DCAP; ++k) g[k] = 0.0;
+  double g_noise = 0.0, g_os = 0.0;
+
+#pragma unroll 1
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+      const int row = tile_row<T>(wm, mt, lane, r);
+      const int gi = ib * NB + row;
+      T xi[DCAP];
+#pragma unroll
+      for (int k = 0; k < DCAP; ++k) xi[k] = k < d ? ui[row * ldu + k] : T(0);
+      const T a_i = ai[row];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int col = tile_col(wn, nt, lane);
+        const int gj = jb * NB + col;
+        const T kin = acc.v[mt][nt][r];
+        if (Kinv && gj >= gi) Kinv[(int64_t)lat * strideK + (int64_t)gi * ldk + gj] = kin;
+        if (kinv_diag && gi == gj) kinv_diag[(int64_t)lat * n_pad + gi] = kin;
+        if (gi < n && gj < n && gj >= gi) {
+          const T wij = a_i * aj[col] - kin;
+          T df2[DCAP];
+          T r2 = T(0);
+#pragma unroll
+          for (int k = 0; k < DCAP; ++k) {
+            T df = k < d ? xi[k] - uj[col * ldu + k] : T(0);
+            df2[k] = df * df;
+            r2 += df2[k];
+          }
+          T val, base;
+          kern_value_base<T>(kind, r2, val, base);
+          if (gi == gj) {
+            g_noise += (double)wij;
+            g_os += (double)(wij * val);
+          } else {
+            const T c = T(2) * wij * os * base;          // symmetric pair (i,j),(j,i)
+#pragma unroll
+            for (int k = 0; k < DCAP; ++k) g[k] += (double)(c * df2[k]);
+            g_os += (double)(T(2) * wij * val);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- workgroup reduction of the d+2 partial sums (wave shuffles, then LDS across 4 waves)
+  __syncthreads();
+  double *red = reinterpret_cast<double *>(smem);    // [4][GP]
+  auto wave_sum = [&](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+  };
+#pragma unroll
+  for (int k = 0; k < DCAP; ++k) {
+    double s = wave_sum(g[k]);
+    if (lane == 0) red[wave * GP + k] = s;
+  }
+  {
+    double s = wave_sum(g_noise);
+    if (lane == 0) red[wave * GP + MAX_DIM] = s;
+    s = wave_sum(g_os);
+    if (lane == 0) red[wave * GP + MAX_DIM + 1] = s;
+  }
+  __syncthreads();
+  double *out = partials + (((int64_t)lat * m + ib) * m + jb) * GP;
+  if (tid < GP) {
+    const bool live = tid < DCAP || tid >= MAX_DIM;
+    out[tid] = live ? red[tid] + red[GP + tid] + red[2 * GP + tid] + red[3 * GP + tid] : 0.0;
+  }
+}
+
+// grad[lat][k] = 1/2 * sum over upper tiles of partials, with the 1/ell_k factor for lengthscales.
+// grid (q); fixed summation order.
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_reduce_grad(const double *__restrict__ partials, int m, int d,
+                                                           const T *__restrict__ ell, double *__restrict__ grad) {
+  __shared__ double red[NTHREADS];
+  const int lat = blockIdx.x;
+  const int ntile = m * m;
+  const int slot = threadIdx.x % GP;          // 34 slots; 256 / 34 = 7 groups (+ remainder idle)
+  const int grp = threadIdx.x / GP;
+  constexpr int NG = NTHREADS / GP;
+  double s = 0.0;
+  if (grp < NG) {
+    for (int t = grp; t < ntile; t += NG) {
+      int ib = t / m, jb = t % m;
+      if (jb >= ib) s += partials[((int64_t)lat * ntile + t) * GP + slot];
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < GP) {
+    double tot = 0.0;
+    for (int gq = 0; gq < NG; ++gq) tot += red[gq * GP + threadIdx.x];
+    const int k = threadIdx.x;
+    if (k < d) grad[(int64_t)lat * (d + 2) + k] = 0.5 * tot / (double)ell[(int64_t)lat * d + k];
+    else if (k == MAX_DIM) grad[(int64_t)lat * (d + 2) + d] = 0.5 * tot;
+    else if (k == MAX_DIM + 1) grad[(int64_t)lat * (d + 2) + d + 1] = 0.5 * tot;
+  }
+}
+
+template <typename T>
+int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, const T *alpha, const T *X, int n,
+                   int d, const T *ell, const T *oscale, double *grad, T *Kinv, int64_t ldk, int64_t strideK,
+                   T *kinv_diag, void *partials, int q, void *stream) {
+  PLMC_REQUIRE(kind >= 0 && kind <= 3, "unknown kernel kind");
+  PLMC_REQUIRE(W && alpha && X && ell && grad && partials, "null pointer");
+  PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0 && ldw % NB == 0 && n <= n_pad && n > n_pad - NB, "n_pad must be plmc_pad(n)");
+  PLMC_REQUIRE(d > 0 && d <= MAX_DIM && q > 0, "need 0<d<=plmc_max_dim(), q>0");
+  PLMC_REQUIRE(!Kinv || (ldk >= n_pad), "ldk too small");
+  PLMC_REQUIRE(aligned16(W), "unaligned W");
+  hipStream_t st = (hipStream_t)stream;
+  const int m = (int)(n_pad / NB);
+  dim3 grid(m, m, q), block(NTHREADS);
+  double *part = reinterpret_cast<double *>(partials);
+#define PLMC_LAUNCH_KG(DC)                                                                                          \
+  hipLaunchKernelGGL((k_kinv_grad<T, DC>), grid, block, 0, st, kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell,   \
+                     oscale, Kinv, ldk, strideK, kinv_diag, part)
+  if (d <= 4) PLMC_LAUNCH_KG(4);
+  else if (d <= 8) PLMC_LAUNCH_KG(8);
+  else if (d <= 16) PLMC_LAUNCH_KG(16);
+  else PLMC_LAUNCH_KG(32);
+#undef PLMC_LAUNCH_KG
+  hipLaunchKernelGGL(k_reduce_grad<T>, dim3(q), dim3(NTHREADS), 0, st, part, m, d, ell, grad);
+  return launch_status(__func__);
+}
+
+}  // namespace plmc
+
+extern "C" {
+int64_t plmc_grad_scratch_bytes(int64_t n_pad, int q) {
+  int64_t m = n_pad / plmc::NB;
+  return m * m * (int64_t)q * plmc::GP * (int64_t)sizeof(double);
+}
+int plmc_kinv_grad_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW, const float *alpha,
+                       const float *X, int n, int d, const float *ell, const float *oscale, double *grad,
+                       float *Kinv, int64_t ldk, int64_t strideK, float *kinv_diag, void *partials, int q,
+                       void *stream) {
+  return plmc::kinv_grad_impl<float>(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk,
+                                     strideK, kinv_diag, partials, q, stream);
+}
+int plmc_kinv_grad_f64(int kind, const double *W, int64_t n_pad, int64_t ldw, int64_t strideW, const double *alpha,
+                       const double *X, int n, int d, const double *ell, const double *oscale, double *grad,
+                       double *Kinv, int64_t ldk, int64_t strideK, double *kinv_diag, void *partials, int q,
+                       void *stream) {
+  return plmc::kinv_grad_impl<double>(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk,
+                                      strideK, kinv_diag, partials, q, stream);
+}
+}

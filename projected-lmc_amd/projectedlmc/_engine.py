@@ -1,0 +1,218 @@
+"""Host side of the exact-GP hot path: torch-owned workspaces + autograd wrappers around the
+C ABI (include/plmc.h).  PyTorch is plumbing here (device memory, streams, autograd graph);
+all n x n work happens in the HIP library.
+
+What it replaces in the reference: the gpytorch evaluation chain behind
+`latent_output.log_prob(proj_target)` (projected_lmc.py:1200-1201), ExactMarginalLogLikelihood
+(experiments.py:233) and `loss.backward()` (experiments.py:270); see SURVEY.md 8a rows a1-a4.
+"""
+import math
+import warnings
+
+import torch
+
+from . import _hip
+from . import settings
+
+LOG2PI = math.log(2.0 * math.pi)
+
+
+class Workspace:
+    """Caller-owned device buffers for q latent GPs on n points with naug augmented columns.
+    Layout documented in include/plmc.h."""
+
+    def __init__(self, n, q, naug, dtype, device, need_grad=True):
+        L = _hip.lib()
+        self.n, self.q, self.naug, self.dtype, self.device = n, q, naug, dtype, device
+        self.NB = L.cdll.plmc_block()
+        self.n_pad = int(L.cdll.plmc_pad(n))
+        self.naug_pad = int(L.cdll.plmc_pad(naug)) if naug > 0 else 0
+        self.lda = self.n_pad + self.naug_pad
+        self.strideA = self.n_pad * self.lda
+        self.m = self.n_pad // self.NB
+        self.A = torch.empty(q, self.n_pad, self.lda, dtype=dtype, device=device)
+        self.Vd = torch.empty(q, self.m, self.NB, self.NB, dtype=dtype, device=device)
+        self.logdet = torch.empty(q, dtype=torch.float64, device=device)
+        self.quad = torch.empty(q, dtype=torch.float64, device=device)
+        self.info = torch.empty(q, dtype=torch.int32, device=device)
+        self.z = torch.empty(q, self.n_pad, dtype=dtype, device=device)
+        self.W = self.alpha = self.partials = None
+        if need_grad:
+            self.ensure_grad_buffers()
+
+    def ensure_grad_buffers(self):
+        if self.W is None:
+            L = _hip.lib()
+            self.ldw = self.n_pad
+            self.strideW = self.n_pad * self.ldw
+            self.W = torch.empty(self.q, self.n_pad, self.ldw, dtype=self.dtype, device=self.device)
+            self.alpha = torch.empty(self.q, self.n_pad, dtype=self.dtype, device=self.device)
+            nbytes = int(L.cdll.plmc_grad_scratch_bytes(self.n_pad, self.q))
+            self.partials = torch.empty(nbytes // 8, dtype=torch.float64, device=self.device)
+
+
+_ws_cache = {}
+
+
+def get_workspace(n, q, naug, dtype, device, need_grad):
+    key = (n, q, naug, dtype, device.index)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        if len(_ws_cache) > 4:
+            _ws_cache.clear()
+        ws = Workspace(n, q, naug, dtype, device, need_grad)
+        _ws_cache[key] = ws
+    elif need_grad:
+        ws.ensure_grad_buffers()
+    return ws
+
+
+def free_workspaces():
+    _ws_cache.clear()
+
+
+def _contig(t):
+    return None if t is None else t.detach().contiguous()
+
+
+def factorize(kind, X, ell, oscale, noise, rhs, ws, Xs=None):
+    """Assemble Khat (+ rhs / cross-covariance columns) and run the blocked Cholesky.
+    rhs: (q, nrhs, n) or None.  Returns nothing; results live in ws (A, Vd, logdet, info)."""
+    L = _hip.lib()
+    dt, dev = ws.dtype, ws.device
+    st = _hip.stream_ptr(dev)
+    k = _hip.KIND[kind]
+    q, n, d = ws.q, ws.n, X.shape[1]
+    L.call("plmc_assemble", dt, k, _hip.ptr(X), n, d, _hip.ptr(ell), _hip.ptr(oscale), _hip.ptr(noise),
+           _hip.ptr(ws.A), ws.lda, ws.strideA, q, st)
+    nrhs = 0 if rhs is None else rhs.shape[1]
+    if ws.naug_pad > 0:
+        L.call("plmc_write_rhs", dt, _hip.ptr(rhs), nrhs, n, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, 1, q, st)
+    if Xs is not None:
+        L.call("plmc_assemble_cross", dt, k, _hip.ptr(X), n, _hip.ptr(Xs), Xs.shape[0], d, _hip.ptr(ell),
+               _hip.ptr(oscale), _hip.ptr(ws.A), ws.lda, ws.strideA, ws.n_pad + nrhs, ws.n_pad, q, st)
+    L.call("plmc_potrf", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.naug, ws.strideA, _hip.ptr(ws.Vd),
+           _hip.ptr(ws.logdet), _hip.ptr(ws.info), q, st)
+
+
+def factorize_checked(kind, X, ell, oscale, noise, rhs, ws, Xs=None):
+    """factorize + the jitter ladder of gpytorch's psd_safe_cholesky [gpytorch-knowledge]:
+    on a non-PD pivot retry with noise + jitter * 10^k (jitter 1e-6 fp32 / 1e-8 fp64) up to
+    settings.cholesky_max_tries, warning each time; raise if still not PD.
+    (reference call sites: experiments.py:265, projected_lmc.py:416,649)."""
+    factorize(kind, X, ell, oscale, noise, rhs, ws, Xs)
+    if not settings.check_cholesky.on():
+        return 0.0
+    info = ws.info.cpu()
+    if not bool(info.any()):
+        return 0.0
+    base = settings.cholesky_jitter.value(ws.dtype)
+    tries = settings.cholesky_max_tries.value()
+    for i in range(tries):
+        jit = base * (10 ** i)
+        warnings.warn("A not p.d., added jitter of %.1e to the diagonal" % jit, RuntimeWarning)
+        factorize(kind, X, ell, oscale, noise + jit, rhs, ws, Xs)
+        info = ws.info.cpu()
+        if not bool(info.any()):
+            return jit
+    raise RuntimeError("Matrix not positive definite after repeatedly adding jitter up to %.1e "
+                       "(first failing pivot per latent: %s)" % (jit, info.tolist()))
+
+
+class ExactLatentLogProb(torch.autograd.Function):
+    """log N(y_i; 0, os_i k(X,X; ell_i) + noise_i I) for a batch of q independent GPs, with the
+    analytic gradient computed in the same pass.
+
+    forward(X (n,d), ell (q,d), oscale (q)|None, noise (q), y (q,n), kind) -> (q,)
+    """
+
+    @staticmethod
+    def forward(ctx, X, ell, oscale, noise, y, kind):
+        _hip.require_device(X, ell, noise, y)
+        L = _hip.lib()
+        dt, dev = y.dtype, y.device
+        if dt not in (torch.float32, torch.float64):
+            raise TypeError("projectedlmc hot path supports float32 and float64 tensors")
+        q, n = y.shape
+        d = X.shape[1]
+        if d > L.cdll.plmc_max_dim():
+            raise ValueError("input dimension %d exceeds plmc_max_dim()=%d" % (d, L.cdll.plmc_max_dim()))
+        need_grad = any(ctx.needs_input_grad[1:5])
+        Xc, ellc, osc, nzc, yc = _contig(X), _contig(ell), _contig(oscale), _contig(noise), _contig(y)
+        Xc = Xc.to(dt)
+        ws = get_workspace(n, q, 1, dt, dev, need_grad)
+        st = _hip.stream_ptr(dev)
+        jit = factorize_checked(kind, Xc, ellc, osc, nzc, yc.reshape(q, 1, n), ws)
+        L.call("plmc_extract_col", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, 0, _hip.ptr(ws.z),
+               _hip.ptr(ws.quad), q, st)
+        logp = -0.5 * (ws.quad + ws.logdet + n * LOG2PI)
+        if need_grad:
+            L.call("plmc_trtri", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, _hip.ptr(ws.Vd), _hip.ptr(ws.W),
+                   ws.ldw, ws.strideW, q, st)
+            L.call("plmc_wt_matvec", dt, _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.z),
+                   _hip.ptr(ws.alpha), q, st)
+            grad = torch.empty(q, d + 2, dtype=torch.float64, device=dev)
+            L.call("plmc_kinv_grad", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW,
+                   _hip.ptr(ws.alpha), _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad),
+                   None, 0, 0, None, _hip.ptr(ws.partials), q, st)
+            ctx.save_for_backward(grad, ws.alpha[:, :n].clone())
+        ctx.d = d
+        ctx.has_os = oscale is not None
+        ctx.jitter = jit
+        return logp.to(dt)
+
+    @staticmethod
+    def backward(ctx, gout):
+        grad, alpha = ctx.saved_tensors
+        d = ctx.d
+        dt = alpha.dtype
+        g64 = gout.to(torch.float64)
+        g_ell = (g64[:, None] * grad[:, :d]).to(dt)
+        g_noise = (g64 * grad[:, d]).to(dt)
+        g_os = (g64 * grad[:, d + 1]).to(dt) if ctx.has_os else None
+        g_y = -(gout[:, None].to(dt) * alpha)
+        return None, g_ell, g_os, g_noise, g_y, None
+
+
+def exact_latent_log_prob(kind, X, ell, oscale, noise, y):
+    return ExactLatentLogProb.apply(X, ell, oscale, noise, y, kind)
+
+
+def exact_posterior(kind, X, ell, oscale, noise, y, Xs, full_cov=False):
+    """Posterior of q zero-mean GPs at Xs from ONE augmented factorization [Khat | y | K*^T]:
+    with v = U^-T k*, z = U^-T y:  mean = v^T z,  cov = K** - v^T v.
+    (ExactGPModel.__call__ in eval mode -> gpytorch DefaultPredictionStrategy; reached from
+    projected_lmc.py:1134.)  Returns (mean (q,ns), var (q,ns) | cov (q,ns,ns))."""
+    _hip.require_device(X, ell, noise, y, Xs)
+    L = _hip.lib()
+    dt, dev = y.dtype, y.device
+    q, n = y.shape
+    ns = Xs.shape[0]
+    Xc, Xsc = _contig(X).to(dt), _contig(Xs).to(dt)
+    ellc, osc, nzc = _contig(ell), _contig(oscale), _contig(noise)
+    ws = get_workspace(n, q, 1 + ns, dt, dev, False)
+    factorize_checked(kind, Xc, ellc, osc, nzc, _contig(y).reshape(q, 1, n), ws, Xs=Xsc)
+    aug = ws.A[:, :, ws.n_pad:ws.n_pad + 1 + ns]                # (q, n_pad, 1+ns) strided view
+    z = aug[:, :, 0]
+    V = aug[:, :, 1:]
+    mean = torch.einsum("qis,qi->qs", V, z)
+    os_ = torch.ones(q, dtype=dt, device=dev) if oscale is None else osc
+    if full_cov:
+        Kss = dense_cross(kind, Xsc, Xsc, ellc, osc)
+        cov = Kss - V.transpose(-1, -2) @ V
+        return mean, cov
+    var = os_[:, None] - (V * V).sum(1)
+    return mean, var
+
+
+def dense_cross(kind, X1, X2, ell, oscale):
+    """Dense k(X1, X2) per latent via the cross-assembly kernel: (q, n1, n2)."""
+    L = _hip.lib()
+    dt, dev = X1.dtype, X1.device
+    q = ell.shape[0]
+    n1, n2, d = X1.shape[0], X2.shape[0], X1.shape[1]
+    out = torch.empty(q, n1, n2, dtype=dt, device=dev)
+    L.call("plmc_assemble_cross", dt, _hip.KIND[kind], _hip.ptr(X1.contiguous()), n1, _hip.ptr(X2.contiguous()), n2, d,
+           _hip.ptr(ell.contiguous()), _hip.ptr(None if oscale is None else oscale.contiguous()), _hip.ptr(out),
+           n2, n1 * n2, 0, n1, q, _hip.stream_ptr(dev))
+    return out

@@ -1,0 +1,96 @@
+"""ctypes binding of the C ABI declared in include/plmc.h (libplmc_hip.so, gfx950).
+
+There is deliberately no fallback: if the shared library is missing or a symbol cannot be
+resolved, importing the hot path raises.  Pointers are taken from torch tensors
+(`tensor.data_ptr()`), the stream from `torch.cuda.current_stream()`.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplmc_hip.so")
+
+KIND = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3}
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_L = _c.c_int64
+
+# name -> argtypes, for the per-dtype entry points (suffix added below)
+_TYPED = {
+    "plmc_assemble": [_I, _P, _I, _I, _P, _P, _P, _P, _L, _L, _I, _P],
+    "plmc_write_rhs": [_P, _I, _I, _P, _L, _L, _I, _I, _I, _P],
+    "plmc_assemble_cross": [_I, _P, _I, _P, _I, _I, _P, _P, _P, _L, _L, _L, _L, _I, _P],
+    "plmc_potrf": [_P, _L, _L, _I, _L, _P, _P, _P, _I, _P],
+    "plmc_extract_col": [_P, _L, _L, _L, _I, _P, _P, _I, _P],
+    "plmc_trtri": [_P, _L, _L, _L, _P, _P, _L, _L, _I, _P],
+    "plmc_wt_matvec": [_P, _L, _L, _L, _P, _P, _I, _P],
+    "plmc_kinv_grad": [_I, _P, _L, _L, _L, _P, _P, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P],
+}
+_PLAIN = {
+    "plmc_version": ([], _I),
+    "plmc_block": ([], _I),
+    "plmc_pad": ([_L], _L),
+    "plmc_max_dim": ([], _I),
+    "plmc_last_error": ([], _c.c_char_p),
+    "plmc_grad_scratch_bytes": ([_L, _I], _L),
+}
+
+
+def exported_symbols():
+    """Every symbol include/plmc.h declares (used by the CPU-side ABI test)."""
+    names = list(_PLAIN)
+    for base in _TYPED:
+        names += [base + "_f32", base + "_f64"]
+    return names
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "projectedlmc: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        for name, (args, res) in _PLAIN.items():
+            fn = getattr(self.cdll, name)
+            fn.argtypes, fn.restype = args, res
+        for base, args in _TYPED.items():
+            for suf in ("_f32", "_f64"):
+                fn = getattr(self.cdll, base + suf)
+                fn.argtypes, fn.restype = args, _I
+
+    def call(self, base, dtype, *args):
+        suf = "_f32" if dtype == torch.float32 else "_f64"
+        rc = getattr(self.cdll, base + suf)(*args)
+        if rc != 0:
+            raise RuntimeError("%s%s failed (%d): %s" % (base, suf, rc, self.cdll.plmc_last_error().decode()))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib
+
+
+def ptr(t):
+    return None if t is None else _c.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    return _c.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "projectedlmc (MI355X build): the exact-GP hot path runs only on ROCm device tensors "
+                "(got a %s tensor); there is no CPU fallback -- move model and data with .cuda()." % t.device.type)

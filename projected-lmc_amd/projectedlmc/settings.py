@@ -1,0 +1,55 @@
+"""The few numerical settings the reference's drivers touch, as context managers with the
+gpytorch names (experiments.py:265,312 `cholesky_max_tries`; README.md:54 `cholesky_jitter`).
+[gpytorch-knowledge] defaults: cholesky_max_tries = 3, cholesky_jitter = 1e-6 (fp32) / 1e-8 (fp64).
+"""
+import torch
+
+
+class _Value:
+    _default = None
+    _stack = None
+
+    def __init__(self, value):
+        self._value = value
+
+    def __enter__(self):
+        type(self)._stack.append(self._value)
+        return self
+
+    def __exit__(self, *exc):
+        type(self)._stack.pop()
+        return False
+
+
+class cholesky_max_tries(_Value):
+    _stack = [3]
+
+    @classmethod
+    def value(cls):
+        return cls._stack[-1]
+
+
+class cholesky_jitter(_Value):
+    """cholesky_jitter(float_value=None, double_value=None) or cholesky_jitter(x) for both."""
+    _stack = [(1e-6, 1e-8)]
+
+    def __init__(self, float_value=None, double_value=None):
+        f, d = type(self)._stack[-1]
+        if float_value is not None and double_value is None:
+            double_value = float_value
+        super().__init__((float_value if float_value is not None else f, double_value if double_value is not None else d))
+
+    @classmethod
+    def value(cls, dtype):
+        f, d = cls._stack[-1]
+        return f if dtype == torch.float32 else d
+
+
+class check_cholesky(_Value):
+    """check_cholesky(False) skips the host read-back of the factorization status (one device
+    sync per step); a non-PD matrix then surfaces as a NaN loss instead of a jitter retry."""
+    _stack = [True]
+
+    @classmethod
+    def on(cls):
+        return cls._stack[-1]

@@ -1,0 +1,105 @@
+"""GPU parity of the HIP hot path (through the C ABI) against the CPU oracle."""
+import pytest
+import torch
+
+from oracle import gp_math as gm
+
+pytestmark = pytest.mark.gpu
+
+KINDS = {"rbf": ("rbf", 2.5), "matern12": ("matern", 0.5), "matern32": ("matern", 1.5), "matern52": ("matern", 2.5)}
+
+
+def _problem(n, d, q, seed=0, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    X = 2 * torch.rand(n, d, generator=g, dtype=torch.float64) - 1
+    y = torch.randn(q, n, generator=g, dtype=torch.float64)
+    ell = 0.3 + 0.5 * torch.rand(q, d, generator=g, dtype=torch.float64)
+    noise = 0.05 + 0.5 * torch.rand(q, generator=g, dtype=torch.float64)
+    osc = 0.5 + torch.rand(q, generator=g, dtype=torch.float64)
+    return X, y, ell, noise, osc
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from projectedlmc import _engine
+    assert torch.cuda.is_available()
+    return _engine
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+@pytest.mark.parametrize("n,d,q", [(128, 2, 1), (200, 3, 2), (517, 8, 3)])
+@pytest.mark.parametrize("use_os", [False, True])
+def test_logprob_and_grad_fp64(eng, kind, n, d, q, use_os):
+    okind, nu = KINDS[kind]
+    X, y, ell, noise, osc = _problem(n, d, q, seed=n + d)
+    if kind == "matern12":
+        pass
+    ref = gm.exact_latent_log_prob_analytic(okind, X, ell, noise, y, osc if use_os else None, nu)
+    dev = torch.device("cuda:0")
+    ell_d = ell.to(dev).requires_grad_()
+    nz_d = noise.to(dev).requires_grad_()
+    y_d = y.to(dev).requires_grad_()
+    os_d = osc.to(dev).requires_grad_() if use_os else None
+    lp = eng.exact_latent_log_prob(kind, X.to(dev), ell_d, os_d, nz_d, y_d)
+    w = torch.linspace(0.5, 1.5, q, dtype=torch.float64)
+    (lp * w.to(dev)).sum().backward()
+    assert torch.allclose(lp.detach().cpu(), ref[0], rtol=1e-10, atol=0), (lp.detach().cpu(), ref[0])
+    assert torch.allclose(ell_d.grad.cpu(), w[:, None] * ref[1], rtol=1e-7, atol=1e-9)
+    assert torch.allclose(nz_d.grad.cpu(), w * ref[2], rtol=1e-7, atol=1e-9)
+    assert torch.allclose(y_d.grad.cpu(), w[:, None] * ref[4], rtol=1e-7, atol=1e-9)
+    if use_os:
+        assert torch.allclose(os_d.grad.cpu(), w * ref[3], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+def test_logprob_and_grad_fp32(eng, kind):
+    """fp32 tolerance: log-prob within 1e-4 relative of the fp64 oracle (BASELINE.json target),
+    gradients within 2e-3 of their max magnitude."""
+    okind, nu = KINDS[kind]
+    n, d, q = 1000, 8, 2
+    X, y, ell, noise, osc = _problem(n, d, q, seed=7)
+    ref = gm.exact_latent_log_prob_analytic(okind, X, ell, noise, y, None, nu)
+    dev = torch.device("cuda:0")
+    f = lambda t: t.to(dev, torch.float32)
+    ell_d = f(ell).requires_grad_()
+    nz_d = f(noise).requires_grad_()
+    y_d = f(y).requires_grad_()
+    lp = eng.exact_latent_log_prob(kind, f(X), ell_d, None, nz_d, y_d)
+    lp.sum().backward()
+    rel = ((lp.detach().cpu().double() - ref[0]) / ref[0]).abs().max()
+    assert rel < 1e-4, rel
+    for got, want in ((ell_d.grad, ref[1]), (nz_d.grad, ref[2]), (y_d.grad, ref[4])):
+        err = (got.cpu().double() - want).abs().max() / want.abs().max()
+        assert err < 2e-3, err
+
+
+def test_posterior_fp64(eng):
+    n, d, q, ns = 300, 3, 2, 77
+    X, y, ell, noise, osc = _problem(n, d, q, seed=3)
+    Xs = 2 * torch.rand(ns, d, dtype=torch.float64) - 1
+    mu, cov = gm.exact_gp_posterior("matern", X, ell, noise, y, Xs, osc, 2.5)
+    dev = torch.device("cuda:0")
+    m1, v1 = eng.exact_posterior("matern52", X.to(dev), ell.to(dev), osc.to(dev), noise.to(dev), y.to(dev), Xs.to(dev))
+    assert torch.allclose(m1.cpu(), mu, rtol=1e-8, atol=1e-10)
+    assert torch.allclose(v1.cpu(), torch.diagonal(cov, dim1=-2, dim2=-1), rtol=1e-7, atol=1e-10)
+    m2, c2 = eng.exact_posterior("matern52", X.to(dev), ell.to(dev), osc.to(dev), noise.to(dev), y.to(dev), Xs.to(dev),
+                                 full_cov=True)
+    assert torch.allclose(c2.cpu(), cov, rtol=1e-7, atol=1e-9)
+
+
+def test_not_pd_is_reported(eng):
+    """A non-PD matrix must walk the jitter ladder (warning) -- duplicate points with ~zero noise."""
+    n, d, q = 130, 2, 1
+    X, y, ell, noise, _ = _problem(n, d, q)
+    X[1] = X[0]
+    dev = torch.device("cuda:0")
+    nz = torch.full((1,), -1e-3, dtype=torch.float64)          # negative "noise": indefinite
+    with pytest.warns(RuntimeWarning):
+        with pytest.raises(RuntimeError):
+            eng.exact_latent_log_prob("rbf", X.to(dev), ell.to(dev), None, nz.to(dev), y.to(dev))
+
+
+def test_cpu_tensors_fail_loudly(eng):
+    X, y, ell, noise, _ = _problem(64, 2, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        eng.exact_latent_log_prob("rbf", X, ell, None, noise, y)
