@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- MLL+grad iterations/sec of the exact Projected-LMC training step
+(BASELINE.json metric).
+
+Workload (configs[2], "C3"): ProjectedGPModel + ProjectedLMCmll, n=8192 points, d=8, p=16 tasks,
+q=8 latents, Matern-5/2, fp32, variant PLMC_fast (experiments.py:211-215), synthetic data with
+the structure of experiments.py:137-167.  One step = the body of experiments.py:264-273:
+zero_grad -> model(X) -> -mll -> backward -> (all-reduce of grads when sharded) -> AdamW step.
+
+N GPUs: the q latent GPs are sharded across ranks (latent i -> rank i mod N), total work fixed
+(strong scaling); the only collective is one small fused all-reduce per step.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+import warnings
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "projected-lmc_amd")]
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}     # MI355X_MICROARCH.md chip table (dense matrix peaks)
+HBM_PEAK_GBS = 8000.0
+
+
+def make_data(n, d, p, q, seed=0, dtype=torch.float32):
+    """X ~ U(-1,1)^(n x d); Y = G H_true (1 - mu_noise) + structured + unstructured noise, mirroring
+    experiments.py:137-167.  Latent draws G use random Fourier features of the Matern-5/2 spectral
+    density (multivariate t, 5 dof) so that no n x n host factorisation is needed at n = 8192."""
+    g = torch.Generator().manual_seed(seed)
+    X = 2 * torch.rand(n, d, generator=g, dtype=torch.float64) - 1
+    lsc = torch.linspace(0.1, 0.5 * math.sqrt(d), q, dtype=torch.float64)
+    nf = 1024
+    G = torch.empty(n, q, dtype=torch.float64)
+    for i in range(q):
+        z = torch.randn(nf, d, generator=g, dtype=torch.float64)
+        u = (torch.randn(nf, 5, generator=g, dtype=torch.float64) ** 2).sum(1, keepdim=True)   # chi^2_5
+        om = z / lsc[i] * torch.sqrt(5.0 / u)
+        ph = 2 * math.pi * torch.rand(nf, generator=g, dtype=torch.float64)
+        w = torch.randn(nf, generator=g, dtype=torch.float64)
+        G[:, i] = math.sqrt(2.0 / nf) * (torch.cos(X @ om.T + ph) @ w)
+    mu_noise, mu_str = 0.1, 0.9
+    H_true = torch.randn(q, p, generator=g, dtype=torch.float64)
+    Y_sig = G @ H_true * (1 - mu_noise)
+    H_hid = torch.randn(q, p, generator=g, dtype=torch.float64)
+    Y_com = torch.randn(n, q, generator=g, dtype=torch.float64) @ H_hid * mu_str
+    lev = torch.rand(p, generator=g, dtype=torch.float64) + 0.1
+    Y_spec = torch.randn(n, p, generator=g, dtype=torch.float64) * torch.sqrt(lev)[None, :] * (1 - mu_str)
+    Y = Y_sig + (Y_com + Y_spec) * mu_noise
+    return X.to(dtype), Y.to(dtype)
+
+
+def cpu_baseline(X, Y, model_cpu_state, n_latents, budget_latents=1):
+    """The oracle ("port": plain torch-CPU restatement, all host threads) timed on a bounded sample
+    of the same step: `budget_latents` of the q latent MLL+gradient evaluations at full n.
+    iters/sec = 1 / (q * t_per_latent)."""
+    from oracle import cpu_step
+    torch.set_num_threads(os.cpu_count() or 1)
+    ell, noise, ytil = model_cpu_state
+    n = X.shape[0]
+    ts = []
+    for i in range(budget_latents + 1):          # first pass = warm-up (thread pools, page-in)
+        j = i % n_latents
+        t0 = time.time()
+        lp, *_ = cpu_step.latent_step("matern", X, ell[j], noise[j], ytil[j], nu=2.5)
+        ts.append(time.time() - t0)
+    t = min(ts[1:]) if len(ts) > 1 else ts[0]
+    # fp64 forward-only value of latent 0 for the log-likelihood relative-error check
+    lp64 = cpu_step.latent_logp("matern", X.double(), ell[0].double(), noise[0].double(), ytil[0].double(), nu=2.5)
+    return dict(value=1.0 / (n_latents * t), unit="iters/sec", cores=torch.get_num_threads(), kind="port",
+                sample="%d of %d latent exact-GP MLL+gradient evaluations at n=%d (fp32 dense Cholesky + inverse, "
+                       "torch CPU), scaled to the full %d-latent step; %.1f s per latent" % (
+                           budget_latents, n_latents, n, n_latents, t)), float(lp64)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--tasks", type=int, default=16)
+    ap.add_argument("--latents", type=int, default=8)
+    ap.add_argument("--variant", default="PLMC_fast", choices=["PLMC_fast", "PLMC"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import projectedlmc as plmc
+    from projectedlmc import _hip, parallel
+
+    n, d, p, q = args.n, args.d, args.tasks, args.latents
+    dt = torch.float32
+    X, Y = make_data(n, d, p, q, seed=0, dtype=dt)
+    kw = dict(BDN=True, diagonal_B=True, scalar_B=True) if args.variant == "PLMC_fast" else dict(BDN=False)
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = plmc.ProjectedGPModel(X, Y, p, q, proj_likelihood=None, mean_type=plmc.ZeroMean,
+                                      kernel_type=plmc.MaternKernel, init_lmc_coeffs=True,
+                                      latent_shard=(rank, world) if world > 1 else None, **kw)
+    # initial state for the CPU baseline / log-lik check (before moving to the device)
+    with torch.no_grad():
+        cpu_state = (model.covar_module.lengthscale.reshape(q, d).clone(), model.projected_noise().clone(),
+                     model.project_data(Y).clone())
+    model = model.to(dev)
+    Xd, Yd = X.to(dev), Y.to(dev)
+    model.train()
+    model.likelihood.train()
+    mll = plmc.ProjectedLMCmll(model.likelihood, model)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2)
+    params = list(model.parameters())
+
+    def step():
+        opt.zero_grad()
+        out = model(Xd)
+        loss = -mll(out, Yd)
+        loss.backward()
+        gl = parallel.sync_loss_and_grads(loss, params)
+        opt.step()
+        return gl
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # per-latent log-prob at the initial parameters (untimed; for the rel-err check vs the fp64 oracle)
+    with torch.no_grad():
+        from projectedlmc import _engine
+        lp_init = _engine.exact_latent_log_prob("matern52", Xd, cpu_state[0].to(dev), None, cpu_state[1].to(dev),
+                                                cpu_state[2].to(dev))
+        lp0_gpu = float(lp_init[0]) if rank == 0 else 0.0
+    first_loss = None
+    for i in range(args.warmup):
+        l0 = step()
+        if first_loss is None:
+            first_loss = float(l0)
+    prof = not args.no_prof
+    if prof:
+        _hip.prof_enable(True)
+        _hip.prof_collect()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    stats = _hip.prof_collect() if prof else {}
+    if prof:
+        _hip.prof_enable(False)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax)
+
+    if rank == 0:
+        its = args.steps / elapsed
+        res = {
+            "metric": "MLL+grad iters/sec, n=8192 16-task LMC", "value": its, "unit": "iters/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: ProjectedGPModel+ProjectedLMCmll exact training step (%s), n=%d d=%d p=%d q=%d "
+                                   "Matern-5/2 fp32; latents sharded q/N per GPU" % (args.variant, n, d, p, q),
+                       "n_points": n, "n_dim": d, "n_tasks": p, "n_latents": q, "parallelism": "latent-shard x%d" % world},
+            "final_loss": float(last),
+        }
+        # ---- roofline of the dominant kernel (largest share of HIP-event time in the timed region)
+        if stats:
+            mf = {k: v for k, v in stats.items() if v["flops"] > 0}
+            dom = max(mf, key=lambda k: mf[k]["ms"])
+            s = mf[dom]
+            ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS["f32"]
+            res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": None,
+                               "avg_launch_ms": s["ms"] / s["launches"], "launches": s["launches"],
+                               "flops_per_launch": s["flops"] / s["launches"]}
+            tot_ms = sum(v["ms"] for v in stats.values())
+            res["kernels"] = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
+                                  "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] > 0 and v["ms"] > 0 else None,
+                                  "gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
+                              for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])}
+            res["kernel_ms_per_step"] = tot_ms / args.steps
+            # whole-step fractions the north_star asks for: F_chol = q n^3/3 over the potrf kernels,
+            # F_step = q n^3 over all dense kernels (local latents only)
+            q_loc = len(range(rank, q, world))
+            chol_ms = sum(stats[k]["ms"] for k in ("k_diag", "k_panel", "k_trail") if k in stats) / args.steps
+            res["cholesky_gemm"] = {"tflops": q_loc * n ** 3 / 3 / (chol_ms * 1e-3) / 1e12, "ms_per_step": chol_ms,
+                                    "frac_of_mfma_peak": q_loc * n ** 3 / 3 / (chol_ms * 1e-3) / 1e12 / peak}
+            res["step_dense"] = {"tflops": q_loc * n ** 3 / (elapsed / args.steps) / 1e12,
+                                 "frac_of_mfma_peak": q_loc * n ** 3 / (elapsed / args.steps) / 1e12 / peak}
+        if world == 1 and not args.no_cpu_baseline:
+            cb, lp_cpu = cpu_baseline(X, Y, cpu_state, q)
+            res["cpu_baseline"] = cb
+            res["speedup_vs_cpu"] = its / cb["value"]
+            res["loglik_rel_err"] = abs(lp0_gpu - lp_cpu) / abs(lp_cpu)
+            res["loglik_check"] = "latent 0 log N(y~;0,K+s2 I) at initial parameters: fp32 HIP %.6f vs fp64 oracle %.6f" % (lp0_gpu, lp_cpu)
+        res["first_loss"] = first_loss
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,19 @@ int plmc_kinv_grad_f64(int kind, const double *W, int64_t n_pad, int64_t ldw, in
                        const double *oscale, double *grad, double *Kinv, int64_t ldk, int64_t strideK,
                        double *kinv_diag, void *partials, int q, void *stream);
 
+/*
+ * Optional per-kernel profiler (measurement only; the reference's counterpart is the wall-clock
+ * `time.time()` around its loops, experiments.py:261,284).  While enabled, every kernel launch is
+ * bracketed by two hipEvents on its launch stream.  plmc_prof_collect() waits for the recorded
+ * events, then returns per kernel class (index < plmc_prof_kernels(), name plmc_prof_name(i)):
+ * total milliseconds, number of launches, and the ALGORITHMIC flops / bytes of those launches;
+ * it clears the record.  This is the only process-global state in the library.
+ */
+int         plmc_prof_enable(int on);         /* returns the previous setting */
+int         plmc_prof_kernels(void);
+const char *plmc_prof_name(int id);
+int         plmc_prof_collect(double *ms, int64_t *launches, double *flops, double *bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,7 +82,10 @@ def init_params(X, Y, n_latents, *, kind="rbf", nu=2.5, init_lmc_coeffs=False, B
     if scalar_B or diagonal_B:
         P["log_B_tilde"] = math.log(noise_init) * torch.ones(p - q, dtype=dt)      # :975/:980
     else:
-        P["B_tilde_inv_chol_raw"] = torch.diag_embed(math.log(1.0 / noise_init) * torch.ones(p - q, dtype=dt))  # :983
+        # :983-984 -- the parameter is created as diag(log(1/noise_init)) and THEN parametrised;
+        # torch stores original = right_inverse(value) (:255-258: log of the diagonal), so the
+        # effective initial B_tilde_inv_chol is diag(log(1/noise_init)), not its exponential.
+        P["B_tilde_inv_chol_raw"] = torch.diag_embed(math.log(math.log(1.0 / noise_init)) * torch.ones(p - q, dtype=dt))
     if not BDN:
         P["M"] = torch.zeros(q, p - q, dtype=dt)                                    # :988
     return P

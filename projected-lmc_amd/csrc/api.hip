@@ -1,4 +1,6 @@
-// api.hip -- library identification and error text.
+// api.hip -- library identification, error text, and the optional per-kernel HIP-event profiler.
+#include <vector>
+
 #include "api_common.hpp"
 #include "../../include/plmc.h"
 
@@ -6,6 +8,36 @@ namespace plmc {
 char *err_buf() {
   static thread_local char buf[256] = {0};
   return buf;
+}
+
+// ---- profiler: when enabled, every kernel launch is bracketed by two hipEvents recorded on the
+// launch stream; plmc_prof_collect() synchronises them and accumulates time and algorithmic work
+// per kernel class.  Off by default (no events, no state).
+static const char *kProfNames[PK_COUNT] = {"k_assemble", "k_write_rhs", "k_assemble_cross", "k_diag",   "k_panel",
+                                           "k_trail",    "k_wdiag",     "k_trtri_row",      "k_extract_col",
+                                           "k_wt_matvec", "k_kinv_grad", "k_reduce_grad"};
+struct ProfRec { int id; hipEvent_t a, b; double flops, bytes; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_free;
+
+static hipEvent_t get_event() {
+  if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
+ProfScope::ProfScope(int id, hipStream_t st, double flops, double bytes) : idx_(-1), st_(st) {
+  if (!g_prof_on || g_recs.size() >= (1u << 20)) return;
+  ProfRec r{id, get_event(), get_event(), flops, bytes};
+  if (!r.a || !r.b) return;
+  (void)hipEventRecord(r.a, st);
+  g_recs.push_back(r);
+  idx_ = (long)g_recs.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (idx_ >= 0) (void)hipEventRecord(g_recs[idx_].b, st_);
 }
 }  // namespace plmc
 
@@ -15,4 +47,26 @@ int plmc_block(void) { return plmc::NB; }
 int64_t plmc_pad(int64_t n) { return (n + plmc::NB - 1) / plmc::NB * plmc::NB; }
 int plmc_max_dim(void) { return plmc::MAX_DIM; }
 const char *plmc_last_error(void) { return plmc::err_buf(); }
+
+int plmc_prof_enable(int on) {
+  int prev = plmc::g_prof_on;
+  plmc::g_prof_on = on != 0;
+  return prev;
+}
+int plmc_prof_kernels(void) { return plmc::PK_COUNT; }
+const char *plmc_prof_name(int id) { return (id >= 0 && id < plmc::PK_COUNT) ? plmc::kProfNames[id] : ""; }
+int plmc_prof_collect(double *ms, int64_t *launches, double *flops, double *bytes) {
+  using namespace plmc;
+  for (int i = 0; i < PK_COUNT; ++i) { ms[i] = 0; launches[i] = 0; flops[i] = 0; bytes[i] = 0; }
+  for (auto &r : g_recs) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+      ms[r.id] += t; launches[r.id] += 1; flops[r.id] += r.flops; bytes[r.id] += r.bytes;
+    }
+    g_free.push_back(r.a);
+    g_free.push_back(r.b);
+  }
+  g_recs.clear();
+  return 0;
+}
 }

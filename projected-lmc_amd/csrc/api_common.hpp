@@ -30,6 +30,19 @@ inline int launch_status(const char *fn) {
 #define PLMC_REQUIRE(cond, msg) \
   do { if (!(cond)) return plmc::fail(__func__, msg); } while (0)
 
+// kernel classes known to the optional profiler (api.hip)
+enum ProfKernel { PK_ASSEMBLE, PK_WRITE_RHS, PK_CROSS, PK_DIAG, PK_PANEL, PK_TRAIL, PK_WDIAG, PK_TRTRI, PK_EXTRACT,
+                  PK_WTMV, PK_KINV_GRAD, PK_REDUCE, PK_COUNT };
+
+// Brackets the launches made while it is alive with two hipEvents (no-op unless plmc_prof_enable(1)).
+// flops / bytes = ALGORITHMIC work of the bracketed launch (DESIGN.md gives the formulas).
+struct ProfScope {
+  ProfScope(int id, hipStream_t st, double flops, double bytes);
+  ~ProfScope();
+  long idx_;
+  hipStream_t st_;
+};
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace plmc

@@ -122,6 +122,7 @@ int assemble_impl(int kind, const T *X, int n, int d, const T *ell, const T *osc
   PLMC_REQUIRE(strideA >= n_pad * lda || q == 1, "strideA too small");
   const int m = (int)(n_pad / NB);
   size_t smem = 2 * NB * (d + 1) * sizeof(T);
+  ProfScope ps(PK_ASSEMBLE, (hipStream_t)stream, 0.0, q * ((double)n_pad * n_pad / 2) * sizeof(T));
   hipLaunchKernelGGL(k_assemble<T>, dim3(m, m, q), dim3(NTHREADS), smem, (hipStream_t)stream, kind, X, n, d, ell,
                      oscale, noise, A, lda, strideA);
   return launch_status(__func__);
@@ -135,6 +136,7 @@ int write_rhs_impl(const T *rhs, int nrhs, int n, T *A, int64_t lda, int64_t str
   PLMC_REQUIRE(lda > n_pad && lda % NB == 0, "no augmented block (lda must exceed n_pad)");
   PLMC_REQUIRE(c0 >= 0 && nrhs >= 0 && n_pad + c0 + nrhs <= lda, "rhs columns exceed the augmented block");
   const int64_t tot = n_pad * (lda - n_pad);
+  ProfScope ps(PK_WRITE_RHS, (hipStream_t)stream, 0.0, q * (double)tot * sizeof(T));
   hipLaunchKernelGGL(k_write_rhs<T>, dim3((unsigned)((tot + 255) / 256), q), dim3(256), 0, (hipStream_t)stream, rhs,
                      nrhs, n, A, n_pad, lda, strideA, c0, zero_fill);
   return launch_status(__func__);
@@ -147,6 +149,7 @@ int assemble_cross_impl(int kind, const T *X, int n, const T *Xs, int ns, int d,
   PLMC_REQUIRE(X && Xs && ell && Out, "null pointer");
   PLMC_REQUIRE(n > 0 && ns > 0 && q > 0 && d > 0 && d <= MAX_DIM, "bad sizes");
   PLMC_REQUIRE(n_rows >= n && col0 >= 0 && col0 + ns <= ldo, "cross block exceeds the output buffer");
+  ProfScope ps(PK_CROSS, (hipStream_t)stream, 0.0, q * (double)n_rows * ns * sizeof(T));
   hipLaunchKernelGGL(k_assemble_cross<T>, dim3((ns + 63) / 64, (unsigned)((n_rows + 3) / 4), q), dim3(NTHREADS), 0,
                      (hipStream_t)stream, kind, X, n, Xs, ns, d, ell, oscale, Out, n_rows, ldo, strideO, col0);
   return launch_status(__func__);

@@ -222,13 +222,22 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   }
   for (int k = 0; k < m; ++k) {
     const int Ttr = m - k - 1;
-    hipLaunchKernelGGL(k_diag<T>, dim3(q), dim3(DIAG_THREADS), diag_smem, st, A, lda, strideA, k, Vd, strideV, logdet,
-                       info);
-    if (Ttr + Taug > 0)
+    const double nb3 = (double)NB * NB * NB, nt = (double)Ttr * NB;
+    {
+      ProfScope ps(PK_DIAG, st, q * 2.0 * nb3 / 3.0, q * 3.0 * NB * NB * sizeof(T));
+      hipLaunchKernelGGL(k_diag<T>, dim3(q), dim3(DIAG_THREADS), diag_smem, st, A, lda, strideA, k, Vd, strideV,
+                         logdet, info);
+    }
+    if (Ttr + Taug > 0) {
+      ProfScope ps(PK_PANEL, st, q * (nt + naug) * NB * NB, q * 2.0 * (nt + naug) * NB * sizeof(T));
       hipLaunchKernelGGL(k_panel<T>, dim3(Ttr + Taug, q), dim3(NTHREADS), 0, st, A, n_pad, lda, strideA, k, Ttr, Vd,
                          strideV);
-    if (Ttr > 0)
+    }
+    if (Ttr > 0) {
+      ProfScope ps(PK_TRAIL, st, q * (nt * nt * NB + 2.0 * nt * naug * NB),
+                   q * 2.0 * (nt * nt / 2 + nt * naug) * sizeof(T));
       hipLaunchKernelGGL(k_trail<T>, dim3(Ttr + Taug, Ttr, q), dim3(NTHREADS), 0, st, A, n_pad, lda, strideA, k, Ttr);
+    }
   }
   return launch_status(__func__);
 }
@@ -242,10 +251,16 @@ int trtri_impl(const T *A, int64_t n_pad, int64_t lda, int64_t strideA, const T 
   hipStream_t st = (hipStream_t)stream;
   const int m = (int)(n_pad / NB);
   const int64_t strideV = (int64_t)m * NB * NB;
-  hipLaunchKernelGGL(k_wdiag<T>, dim3(m, q), dim3(NTHREADS), 0, st, Vd, strideV, W, ldw, strideW);
-  for (int k = 1; k < m; ++k)
+  {
+    ProfScope ps(PK_WDIAG, st, 0.0, q * 2.0 * m * NB * NB * sizeof(T));
+    hipLaunchKernelGGL(k_wdiag<T>, dim3(m, q), dim3(NTHREADS), 0, st, Vd, strideV, W, ldw, strideW);
+  }
+  for (int k = 1; k < m; ++k) {
+    const double kn = (double)k * NB;
+    ProfScope ps(PK_TRTRI, st, q * (NB * kn * kn + (double)NB * NB * kn), q * (kn * kn / 2 + 2.0 * kn * NB) * sizeof(T));
     hipLaunchKernelGGL(k_trtri_row<T>, dim3(k, q), dim3(NTHREADS), 0, st, A, lda, strideA, Vd, strideV, W, ldw,
                        strideW, k);
+  }
   return launch_status(__func__);
 }
 
@@ -254,6 +269,7 @@ int extract_col_impl(const T *A, int64_t n_pad, int64_t lda, int64_t strideA, in
                      void *stream) {
   PLMC_REQUIRE(A && z && quad, "null pointer");
   PLMC_REQUIRE(c >= 0 && n_pad + c < lda, "column outside the augmented block");
+  ProfScope ps(PK_EXTRACT, (hipStream_t)stream, 0.0, q * 2.0 * n_pad * sizeof(T));
   hipLaunchKernelGGL(k_extract_col<T>, dim3(q), dim3(NTHREADS), 0, (hipStream_t)stream, A, n_pad, lda, strideA, c, z,
                      quad);
   return launch_status(__func__);
@@ -264,6 +280,7 @@ int wt_matvec_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, cons
                    void *stream) {
   PLMC_REQUIRE(W && z && alpha, "null pointer");
   PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0, "n_pad must be a multiple of NB");
+  ProfScope ps(PK_WTMV, (hipStream_t)stream, q * (double)n_pad * n_pad, q * ((double)n_pad * n_pad / 2) * sizeof(T));
   hipLaunchKernelGGL(k_wt_matvec<T>, dim3((unsigned)(n_pad / 64), q), dim3(NTHREADS), 0, (hipStream_t)stream, W,
                      n_pad, ldw, strideW, z, alpha);
   return launch_status(__func__);

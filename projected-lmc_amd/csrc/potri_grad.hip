@@ -177,12 +177,19 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
 #define PLMC_LAUNCH_KG(DC)                                                                                          \
   hipLaunchKernelGGL((k_kinv_grad<T, DC>), grid, block, 0, st, kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell,   \
                      oscale, Kinv, ldk, strideK, kinv_diag, part)
-  if (d <= 4) PLMC_LAUNCH_KG(4);
-  else if (d <= 8) PLMC_LAUNCH_KG(8);
-  else if (d <= 16) PLMC_LAUNCH_KG(16);
-  else PLMC_LAUNCH_KG(32);
+  {
+    const double np = (double)n_pad;
+    ProfScope ps(PK_KINV_GRAD, st, q * np * np * np / 3.0, q * (np * np / 2) * sizeof(T));
+    if (d <= 4) PLMC_LAUNCH_KG(4);
+    else if (d <= 8) PLMC_LAUNCH_KG(8);
+    else if (d <= 16) PLMC_LAUNCH_KG(16);
+    else PLMC_LAUNCH_KG(32);
+  }
 #undef PLMC_LAUNCH_KG
-  hipLaunchKernelGGL(k_reduce_grad<T>, dim3(q), dim3(NTHREADS), 0, st, part, m, d, ell, grad);
+  {
+    ProfScope ps(PK_REDUCE, st, 0.0, (double)plmc_grad_scratch_bytes(n_pad, q) / 2);
+    hipLaunchKernelGGL(k_reduce_grad<T>, dim3(q), dim3(NTHREADS), 0, st, part, m, d, ell, grad);
+  }
   return launch_status(__func__);
 }
 

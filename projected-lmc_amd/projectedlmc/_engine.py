@@ -71,8 +71,13 @@ def free_workspaces():
     _ws_cache.clear()
 
 
-def _contig(t):
-    return None if t is None else t.detach().contiguous()
+def _contig(t, dtype=None):
+    if t is None:
+        return None
+    t = t.detach()
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
 
 
 def factorize(kind, X, ell, oscale, noise, rhs, ws, Xs=None):
@@ -138,8 +143,7 @@ class ExactLatentLogProb(torch.autograd.Function):
         if d > L.cdll.plmc_max_dim():
             raise ValueError("input dimension %d exceeds plmc_max_dim()=%d" % (d, L.cdll.plmc_max_dim()))
         need_grad = any(ctx.needs_input_grad[1:5])
-        Xc, ellc, osc, nzc, yc = _contig(X), _contig(ell), _contig(oscale), _contig(noise), _contig(y)
-        Xc = Xc.to(dt)
+        Xc, ellc, osc, nzc, yc = (_contig(t, dt) for t in (X, ell, oscale, noise, y))
         ws = get_workspace(n, q, 1, dt, dev, need_grad)
         st = _hip.stream_ptr(dev)
         jit = factorize_checked(kind, Xc, ellc, osc, nzc, yc.reshape(q, 1, n), ws)
@@ -167,9 +171,9 @@ class ExactLatentLogProb(torch.autograd.Function):
         d = ctx.d
         dt = alpha.dtype
         g64 = gout.to(torch.float64)
-        g_ell = (g64[:, None] * grad[:, :d]).to(dt)
-        g_noise = (g64 * grad[:, d]).to(dt)
-        g_os = (g64 * grad[:, d + 1]).to(dt) if ctx.has_os else None
+        g_ell = g64[:, None] * grad[:, :d]
+        g_noise = g64 * grad[:, d]
+        g_os = g64 * grad[:, d + 1] if ctx.has_os else None
         g_y = -(gout[:, None].to(dt) * alpha)
         return None, g_ell, g_os, g_noise, g_y, None
 
@@ -188,8 +192,7 @@ def exact_posterior(kind, X, ell, oscale, noise, y, Xs, full_cov=False):
     dt, dev = y.dtype, y.device
     q, n = y.shape
     ns = Xs.shape[0]
-    Xc, Xsc = _contig(X).to(dt), _contig(Xs).to(dt)
-    ellc, osc, nzc = _contig(ell), _contig(oscale), _contig(noise)
+    Xc, Xsc, ellc, osc, nzc = (_contig(t, dt) for t in (X, Xs, ell, oscale, noise))
     ws = get_workspace(n, q, 1 + ns, dt, dev, False)
     factorize_checked(kind, Xc, ellc, osc, nzc, _contig(y).reshape(q, 1, n), ws, Xs=Xsc)
     aug = ws.A[:, :, ws.n_pad:ws.n_pad + 1 + ns]                # (q, n_pad, 1+ns) strided view

@@ -37,7 +37,26 @@ _PLAIN = {
     "plmc_max_dim": ([], _I),
     "plmc_last_error": ([], _c.c_char_p),
     "plmc_grad_scratch_bytes": ([_L, _I], _L),
+    "plmc_prof_enable": ([_I], _I),
+    "plmc_prof_kernels": ([], _I),
+    "plmc_prof_name": ([_I], _c.c_char_p),
+    "plmc_prof_collect": ([_P, _P, _P, _P], _I),
 }
+
+
+def prof_enable(on):
+    return lib().cdll.plmc_prof_enable(1 if on else 0)
+
+
+def prof_collect():
+    """-> {kernel name: dict(ms, launches, flops, bytes)} accumulated since the last collect."""
+    L = lib().cdll
+    k = L.plmc_prof_kernels()
+    ms, fl, by = (_c.c_double * k)(), (_c.c_double * k)(), (_c.c_double * k)()
+    la = (_c.c_int64 * k)()
+    L.plmc_prof_collect(ms, la, fl, by)
+    return {L.plmc_prof_name(i).decode(): dict(ms=ms[i], launches=la[i], flops=fl[i], bytes=by[i])
+            for i in range(k) if la[i] > 0}
 
 
 def exported_symbols():

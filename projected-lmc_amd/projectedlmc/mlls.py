@@ -1,0 +1,35 @@
+"""`ExactMarginalLogLikelihood` with gpytorch's contract (experiments.py:233, README.md:45):
+mll(model(X), Y) = likelihood(model(X)).log_prob(Y) / num_data, num_data =
+function_dist.event_shape.numel() [gpytorch-knowledge, v1.11 -- the same expression the
+reference copies at projected_lmc.py:1194].  Priors (`_add_other_terms`) are out of scope
+(no BASELINE config registers any)."""
+import torch
+
+from .distributions import MultivariateNormal
+from .likelihoods import _GaussianLikelihoodBase
+
+
+class MarginalLogLikelihood(torch.nn.Module):
+    def __init__(self, likelihood, model):
+        super().__init__()
+        self.likelihood = likelihood
+        self.model = model
+
+    def _add_other_terms(self, res, params):
+        return res
+
+
+class ExactMarginalLogLikelihood(MarginalLogLikelihood):
+    def __init__(self, likelihood, model):
+        if not isinstance(likelihood, _GaussianLikelihoodBase):
+            raise RuntimeError("Likelihood must be Gaussian for exact inference")
+        super().__init__(likelihood, model)
+
+    def forward(self, function_dist, target, *params):
+        if not isinstance(function_dist, MultivariateNormal):
+            raise RuntimeError("ExactMarginalLogLikelihood can only operate on Gaussian random variables")
+        output = self.likelihood(function_dist, *params)
+        res = output.log_prob(target)
+        res = self._add_other_terms(res, params)
+        num_data = function_dist.event_shape.numel()
+        return res / num_data

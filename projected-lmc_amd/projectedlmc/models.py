@@ -1,0 +1,243 @@
+"""Exact GP model classes: `ExactGPModel` and the helpers it is built from, mirroring the
+reference's constructor-and-forward API (projected_lmc.py:107-201, 264-436) on top of the HIP
+engine instead of gpytorch.
+"""
+import warnings
+
+import torch
+
+from . import _engine
+from . import kernels as _k
+from . import means as _m
+from .distributions import MultivariateNormal, MultitaskMultivariateNormal
+from .likelihoods import GaussianLikelihood
+
+
+# ---------------------------------------------------------------------------------------- helpers
+def handle_covar_(kernel, dim, decomp=None, n_funcs=1, prior_scales=None, prior_width=None, outputscales=True,
+                  ker_kwargs=None):
+    """Kernel factory with the reference's semantics (projected_lmc.py:107-181): an ARD kernel with
+    batch_shape=[n_funcs]; wrapped in a ScaleKernel when `outputscales`.  Lengthscales start at the
+    prior mean when `prior_scales` is given (:169-179).  Additive `decomp` kernels and lengthscale
+    priors in the loss are SURVEY.md 8f "next" rows and raise NotImplementedError."""
+    ker_kwargs = {} if ker_kwargs is None else ker_kwargs
+    if decomp is None:
+        decomp = [list(range(dim))]
+    if len(decomp) > 1:
+        raise NotImplementedError("additive sub-kernel decompositions (decomp) are not built yet (SURVEY.md 8f-4)")
+    if prior_scales is not None and prior_width is None:
+        raise ValueError('A prior width should be provided if a prior mean is')
+    idx = decomp[0]
+    ker = kernel(ard_num_dims=len(idx), active_dims=idx, lengthscale_prior=None,
+                 batch_shape=torch.Size([n_funcs]), **ker_kwargs)
+    covar_module = _k.ScaleKernel(ker, batch_shape=torch.Size([n_funcs])) if outputscales else ker
+    if prior_scales is not None and ker.has_lengthscale:
+        try:
+            scales = prior_scales[0] if isinstance(prior_scales, list) else torch.as_tensor(prior_scales)[idx]
+            ker.lengthscale = scales
+        except Exception:
+            raise ValueError('Provided prior scales were of the wrong shape')
+    return covar_module
+
+
+def init_lmc_coefficients(train_y, n_latents, QR_form=False):
+    """SVD projection of the labels onto the latent task subspace (projected_lmc.py:183-201).
+
+    The reference calls sklearn's randomized_svd(Y^T, q, random_state=0) on the host.  Here the
+    p x p Gram matrix Y^T Y is formed on the device and eigendecomposed exactly: U = eigenvectors
+    (p x q), S = sqrt(eigenvalues); signs follow sklearn's svd_flip convention for this call
+    (largest-magnitude entry of each column of U positive).  Identical to the reference whenever
+    its randomised range finder is exact (q + 10 >= p); otherwise equal up to the randomised
+    method's approximation error.  Returns (U, S) if QR_form else (U S / sqrt(n-1))^T."""
+    n_data, n_tasks = train_y.shape
+    dt = train_y.dtype
+    Y = train_y.to(torch.float64)
+    if n_data >= n_latents:
+        G = Y.T @ Y
+        evals, evecs = torch.linalg.eigh(G)
+        order = torch.argsort(evals, descending=True)[:n_latents]
+        S = evals[order].clamp_min(0).sqrt()
+        U = evecs[:, order]
+        if U.shape[1] < n_latents:                   # asked for more components than tasks
+            raise ValueError("n_latents cannot exceed n_tasks in the SVD initialisation")
+        piv = U.abs().argmax(dim=0)
+        sgn = torch.sign(U[piv, torch.arange(U.shape[1], device=U.device)])
+        sgn[sgn == 0] = 1
+        U = U * sgn[None, :]
+    else:
+        Q, R = torch.linalg.qr(Y.T, mode="complete")
+        S = 1e-3 * torch.ones(n_latents, dtype=torch.float64, device=Y.device)
+        S[:n_data] = torch.diagonal(R)[:n_data]
+        U = Q[:, :n_latents]
+    U, S = U.to(dt), S.to(dt)
+    if QR_form:
+        return U, S
+    return (U * S / (n_data - 1) ** 0.5).T
+
+
+# ------------------------------------------------------------------------------- parametrisations
+class ScalarParam(torch.nn.Module):
+    """All entries equal to the clamped mean of the raw vector (projected_lmc.py:207-218)."""
+
+    def __init__(self, bounds=(1e-16, 1e16)):
+        super().__init__()
+        self.bounds = bounds
+
+    def forward(self, X):
+        return torch.clamp(X.mean(), *self.bounds) * torch.ones_like(X)
+
+    def right_inverse(self, A):
+        return A
+
+
+class PositiveDiagonalParam(torch.nn.Module):
+    """diag(exp(diag X)) (projected_lmc.py:220-227)."""
+
+    def forward(self, X):
+        return torch.diag_embed(torch.diagonal(X).exp())
+
+    def right_inverse(self, A):
+        return torch.diag_embed(torch.diagonal(A).log())
+
+
+class UpperTriangularParam(torch.nn.Module):
+    """triu(X) with exponentiated diagonal (projected_lmc.py:229-240)."""
+
+    def forward(self, X):
+        U = X.triu(1)
+        return U + torch.diag_embed(torch.diagonal(X).exp())
+
+    def right_inverse(self, A):
+        return A.triu(1) + torch.diag_embed(torch.diagonal(A).log())
+
+
+class LowerTriangularParam(torch.nn.Module):
+    """tril(X) with exp(clamp(diagonal)) (projected_lmc.py:242-258)."""
+
+    def __init__(self, bounds=(1e-16, 1e16)):
+        super().__init__()
+        self.bounds = bounds
+
+    def forward(self, X):
+        L = X.tril(-1)
+        return L + torch.diag_embed(torch.clamp(torch.diagonal(X), *self.bounds).exp())
+
+    def right_inverse(self, A):
+        return A.tril(-1) + torch.diag_embed(torch.diagonal(A).log())
+
+
+# ------------------------------------------------------------------------------------- ExactGP base
+class ExactGP(torch.nn.Module):
+    """The slice of gpytorch.models.ExactGP the reference relies on [gpytorch-knowledge]:
+    train_inputs (tuple) / train_targets, `set_train_data`, and `__call__` that returns the prior
+    at the training inputs in train mode and the posterior in eval mode."""
+
+    def __init__(self, train_inputs, train_targets, likelihood):
+        super().__init__()
+        if train_inputs is not None and torch.is_tensor(train_inputs):
+            train_inputs = (train_inputs,)
+        self.train_inputs = None if train_inputs is None else tuple(
+            t.unsqueeze(-1) if t.ndimension() == 1 else t for t in train_inputs)
+        self.train_targets = train_targets
+        self.likelihood = likelihood
+
+    def _apply(self, fn, *args, **kwargs):
+        if self.train_inputs is not None:
+            self.train_inputs = tuple(fn(t) for t in self.train_inputs)
+            self.train_targets = fn(self.train_targets)
+        return super()._apply(fn, *args, **kwargs)
+
+    def set_train_data(self, inputs=None, targets=None, strict=True):
+        if inputs is not None:
+            if torch.is_tensor(inputs):
+                inputs = (inputs,)
+            self.train_inputs = tuple(t.unsqueeze(-1) if t.ndimension() == 1 else t for t in inputs)
+        if targets is not None:
+            self.train_targets = targets
+
+    def _posterior(self, x, full_cov=False):
+        raise NotImplementedError
+
+    def __call__(self, *args, **kwargs):
+        x = args[0]
+        if x.ndimension() == 1:
+            x = x.unsqueeze(-1)
+        if self.training:
+            tx = self.train_inputs[0]
+            if not (x is tx or (x.shape == tx.shape and torch.equal(x, tx))):
+                raise RuntimeError("You must train on the training inputs!")
+            return self.forward(x)
+        return self._posterior(x, **kwargs)
+
+
+class ExactGPModel(ExactGP):
+    """Standard exact GP; a batch of `n_tasks` independent GPs via batch dimensions
+    (projected_lmc.py:264-321)."""
+
+    def __init__(self, train_x, train_y, likelihood, n_tasks=1, prior_scales=None, prior_width=None,
+                 mean_type=_m.ConstantMean, decomp=None, outputscales=False, kernel_type=_k.RBFKernel,
+                 ker_kwargs=None, n_inducing_points=None, **kwargs):
+        super().__init__(train_x, train_y, likelihood)
+        if ker_kwargs is None:
+            ker_kwargs = {}
+        self.dim = self.train_inputs[0].shape[1]
+        self.n_tasks = n_tasks
+        self.batch_lik = isinstance(likelihood, GaussianLikelihood)
+        self.mean_module = mean_type(input_size=self.dim, batch_shape=torch.Size([n_tasks]))
+        self.covar_module = handle_covar_(kernel_type, dim=self.dim, decomp=decomp, prior_scales=prior_scales,
+                                          prior_width=prior_width, outputscales=outputscales, n_funcs=n_tasks,
+                                          ker_kwargs=ker_kwargs)
+        if n_inducing_points is not None:
+            raise NotImplementedError("inducing-point (SGPR) kernels are a SURVEY.md 8f 'next' row")
+
+    def forward(self, x):
+        mean_x = self.mean_module(x)
+        covar_x = self.covar_module(x)
+        if not self.batch_lik and self.n_tasks > 1:
+            return MultitaskMultivariateNormal.from_batch_mvn(MultivariateNormal(mean_x, covar_x))
+        return MultivariateNormal(mean_x, covar_x)
+
+    # -- eval-mode posterior (gpytorch DefaultPredictionStrategy), one augmented factorization
+    def _latent_targets(self):
+        y = self.train_targets
+        n = self.train_inputs[0].shape[0]
+        if y.dim() == 1:
+            return y.reshape(1, n)
+        return y if y.shape[-1] == n and y.shape[0] == self.n_tasks else y.T
+
+    def _posterior(self, x, full_cov=False):
+        tx = self.train_inputs[0]
+        lazy = self.covar_module(tx)
+        lik = self.likelihood
+        if self.batch_lik:
+            noise = lik.noise.reshape(-1)
+        else:
+            noise = torch.diagonal(lik.task_noise_matrix()).reshape(-1)
+        prior_mean = self.mean_module(tx).reshape(self.n_tasks, -1)
+        resid = self._latent_targets() - prior_mean
+        xs = self.covar_module.select(x)
+        mean, v = _engine.exact_posterior(lazy.kind, lazy.x1, lazy.ell.detach(),
+                                          None if lazy.oscale is None else lazy.oscale.detach(),
+                                          noise.detach().to(lazy.ell.dtype), resid.detach(), xs, full_cov=full_cov)
+        mean = mean + self.mean_module(x).reshape(self.n_tasks, -1)
+        cov = v if full_cov else torch.diag_embed(v)
+        if not self.batch_lik and self.n_tasks > 1:
+            return MultitaskMultivariateNormal.from_batch_mvn(MultivariateNormal(mean, cov))
+        if self.n_tasks == 1 and self.train_targets.dim() == 1:
+            return MultivariateNormal(mean[0], cov[0])
+        return MultivariateNormal(mean, cov)
+
+    # -- inspection helpers (projected_lmc.py:324-365)
+    def _base(self):
+        cm = self.covar_module
+        return cm.base_kernel if hasattr(cm, "base_kernel") else cm
+
+    def lscales(self, unpacked=True):
+        scales = self._base().lengthscale.data.squeeze()
+        return scales if unpacked else [scales]
+
+    def outputscale(self, unpacked=False):
+        n_funcs = self.n_latents if hasattr(self, "n_latents") else self.n_tasks
+        res = torch.zeros((n_funcs, 1))
+        res[:, 0] = self.covar_module.outputscale.data.squeeze()
+        return res.squeeze() if unpacked else res

@@ -1,0 +1,352 @@
+"""The Projected LMC model and its loss (reference: projected_lmc.py:819-1241), on the HIP engine.
+
+The p x q projection algebra (QR of the mixing matrix, T = H^+, noise blocks) is tiny and stays in
+torch on the device, exactly where the reference keeps it; everything that touches an n x n
+object -- the q latent exact-GP log-likelihoods, their gradients and the latent posteriors -- runs
+in libplmc_hip.so.  With `latent_shard=(rank, world)` the q independent latent GPs are split
+across ranks and `ProjectedLMCmll` returns this rank's share of the loss.
+"""
+import math
+import warnings
+
+import torch
+from torch.nn.utils import parametrize
+
+from . import _engine
+from . import kernels as _k
+from . import means as _m
+from .constraints import GreaterThan
+from .distributions import MultivariateNormal, MultitaskMultivariateNormal, KroneckerSumCovariance
+from .likelihoods import GaussianLikelihood, MultitaskGaussianLikelihood, _GaussianLikelihoodBase
+from .mlls import ExactMarginalLogLikelihood
+from .models import (ExactGP, ExactGPModel, init_lmc_coefficients, ScalarParam, PositiveDiagonalParam,
+                     UpperTriangularParam, LowerTriangularParam)
+
+
+class LMCMixingMatrix(torch.nn.Module):
+    """Mixing matrix H = Q R (p x q), stored either in bulk (free matrix `H`, re-factored by QR at
+    every call) or as separately parametrised `Q_plus`, `R` (projected_lmc.py:819-890)."""
+
+    def __init__(self, Q_plus, R, bulk=True):
+        super().__init__()
+        p, c = Q_plus.shape
+        if c == p:
+            self.mode = 'Q_plus'
+        elif c == R.shape[0]:
+            self.mode = 'Q'
+        else:
+            raise ValueError('Wrong dimensions for Q_plus : should be n_tasks x n_tasks or n_tasks x n_latents')
+        self.n_latents, self.n_tasks = R.shape[0], p
+        self._size = torch.Size([self.n_latents, self.n_tasks])
+        self.bulk = bulk
+        if bulk:
+            if self.mode == 'Q_plus':
+                R_pad = torch.eye(p, dtype=R.dtype, device=R.device)
+                R_pad[:self.n_latents, :self.n_latents] = R
+                H = Q_plus @ R_pad
+            else:
+                H = Q_plus @ R
+            self.register_parameter("H", torch.nn.Parameter(H))
+        else:
+            self.register_parameter("Q_plus", torch.nn.Parameter(Q_plus))
+            self.register_parameter("R", torch.nn.Parameter(R))
+
+    def Q(self):
+        return self.Q_plus[:, :self.n_latents] if self.mode == 'Q_plus' else self.Q_plus
+
+    def Q_orth(self):
+        return self.Q_plus[:, self.n_latents:]
+
+    def QR(self):
+        q = self.n_latents
+        if self.bulk:
+            Qf, Rf = torch.linalg.qr(self.H)
+            if self.mode == 'Q_plus':
+                return Qf[:, :q], Rf[:q, :q], Qf[:, q:]
+            return Qf, Rf, None
+        return self.Q(), self.R, self.Q_orth()
+
+    def forward(self):
+        if self.bulk:
+            return self.H.T if self.mode == 'Q' else self.H[:, :self.n_latents].T
+        return (self.Q() @ self.R).T
+
+    def size(self, int=None):
+        return self._size[int] if int else self._size
+
+
+class ProjectedGPModel(ExactGPModel):
+    """The projected LMC of the reference article (projected_lmc.py:893-1155)."""
+
+    def __init__(self, train_x, train_y, n_tasks, n_latents, proj_likelihood=None, init_lmc_coeffs=False, BDN=True,
+                 diagonal_B=False, scalar_B=False, diagonal_R=False, mean_type=_m.ConstantMean,
+                 ortho_param='matrix_exp', bulk=True, noise_thresh=-9., noise_init=1e-2, outputscales=False,
+                 eps=1e-3, latent_shard=None, **kwargs):
+        if proj_likelihood is None or proj_likelihood.noise.shape[0] != n_latents:
+            warnings.warn("In projected GP model the dimension of the likelihood is the number of latent processes. "
+                          "Provided likelihood was the wrong shape or None, so it was replaced by a fresh one")
+            proj_likelihood = GaussianLikelihood(batch_shape=torch.Size([n_latents]),
+                                                 noise_constraint=GreaterThan(math.exp(noise_thresh)))
+        super().__init__(train_x, torch.zeros_like(train_y), proj_likelihood, n_tasks=n_latents,
+                         mean_type=_m.ZeroMean, outputscales=outputscales, **kwargs)
+        self.register_buffer('train_y', train_y)
+        if mean_type is not _m.ZeroMean:
+            raise ValueError('Projected GP model does not support non-zero output-wise means for now !')
+
+        n_data, n_tasks = train_y.shape
+        dt, dev = train_y.dtype, train_y.device
+        if init_lmc_coeffs:
+            if scalar_B and BDN:
+                Q_plus, R = init_lmc_coefficients(train_y, n_latents=n_latents, QR_form=True)
+            else:
+                Q_plus, R_padded = init_lmc_coefficients(train_y, n_latents=n_tasks, QR_form=True)
+                R = R_padded[:n_latents]
+        else:
+            fake_coeffs = torch.randn(n_tasks, n_latents)
+            Q_plus, R_padded, _ = torch.linalg.svd(fake_coeffs)
+            Q_plus, R = Q_plus.to(dt).to(dev), R_padded[:n_latents].to(dt).to(dev)
+            if scalar_B and BDN:
+                Q_plus = Q_plus[:, :n_latents]
+        R = torch.diag_embed(R) / math.sqrt(n_data - 1)
+        lmc = LMCMixingMatrix(Q_plus, R, bulk=bulk)
+        if not bulk:
+            lmc = torch.nn.utils.parametrizations.orthogonal(lmc, name="Q_plus", orthogonal_map=ortho_param,
+                                                             use_trivialization=(ortho_param != 'householder'))
+            parametrize.register_parametrization(lmc, "R", PositiveDiagonalParam() if diagonal_R
+                                                 else UpperTriangularParam())
+        self.lmc_coefficients = lmc
+
+        pq = n_tasks - n_latents
+        log_init = math.log(noise_init)
+        if scalar_B:
+            diagonal_B = True
+            self.register_parameter("log_B_tilde", torch.nn.Parameter(log_init * torch.ones(pq, dtype=dt, device=dev)))
+            parametrize.register_parametrization(self, "log_B_tilde", ScalarParam(bounds=(noise_thresh, -noise_thresh)))
+            if BDN:
+                self.register_buffer('Y_squared_norm', (train_y ** 2).sum())
+        elif diagonal_B:
+            self.register_parameter("log_B_tilde", torch.nn.Parameter(log_init * torch.ones(pq, dtype=dt, device=dev)))
+            self.log_B_tilde_constraint = GreaterThan(noise_thresh)      # registered, never applied (:981)
+        else:
+            self.register_parameter("B_tilde_inv_chol", torch.nn.Parameter(
+                torch.diag_embed(-log_init * torch.ones(pq, dtype=dt, device=dev))))
+            parametrize.register_parametrization(self, "B_tilde_inv_chol",
+                                                 LowerTriangularParam(bounds=(noise_thresh, -noise_thresh)))
+        self.diagonal_B, self.scalar_B = diagonal_B, scalar_B
+        if not BDN:
+            self.register_parameter("M", torch.nn.Parameter(torch.zeros((n_latents, pq), dtype=dt, device=dev)))
+        self.n_tasks, self.n_latents = n_tasks, n_latents
+        self.latent_dim = -1
+        self.eps = eps
+        self.set_latent_shard(latent_shard)
+
+    # ------------------------------------------------------------------ latent sharding (multi-GPU)
+    def set_latent_shard(self, shard):
+        """shard = (rank, world) -> this process owns latents rank, rank+world, ...  (None = all)."""
+        if shard is None:
+            self.latent_ids = None
+        else:
+            rank, world = shard
+            self.latent_ids = list(range(rank, self.n_latents, world))
+        self.latent_shard = shard
+
+    # ------------------------------------------------------------------------------ small algebra
+    def projected_noise(self):
+        return self.likelihood.noise.squeeze(-1)
+
+    def projection_matrix(self):
+        """T (p x q) with Y T = projected data (projected_lmc.py:1003-1012)."""
+        Q, R, Q_orth = self.lmc_coefficients.QR()
+        H_pinv = torch.linalg.solve_triangular(R.T, Q, upper=False, left=False)
+        if hasattr(self, "M"):
+            return H_pinv + Q_orth @ self.M.T * self.projected_noise()[None, :]
+        return H_pinv
+
+    def project_data(self, data):
+        """(q x n) projected observations (projected_lmc.py:1014-1021)."""
+        Q, R, Q_orth = self.lmc_coefficients.QR()
+        out = torch.linalg.solve_triangular(R, Q.T @ data.T, upper=True)
+        if hasattr(self, "M"):
+            out = out + self.projected_noise()[:, None] * self.M @ Q_orth.T @ data.T
+        return out
+
+    def _B_tilde_root(self):
+        pq = self.n_tasks - self.n_latents
+        if self.diagonal_B:
+            return torch.diag_embed(torch.exp(self.log_B_tilde / 2))
+        eye = torch.eye(pq, dtype=self.B_tilde_inv_chol.dtype, device=self.B_tilde_inv_chol.device)
+        return torch.linalg.solve_triangular(self.B_tilde_inv_chol, eye, upper=False).T
+
+    def full_noise_covariance(self):
+        """Task-space noise Sigma (p x p) (projected_lmc.py:1026-1060)."""
+        Q, R, Q_orth = self.lmc_coefficients.QR()
+        QRm = Q @ R
+        sp = self.projected_noise()
+        p = self.n_tasks
+        if hasattr(self, "M"):
+            Bt = self._B_tilde_root()
+            Bt = Bt @ Bt.T
+            B_term = Q_orth @ Bt @ Q_orth.T
+            M_term = -QRm @ (sp[:, None] * self.M) @ Bt @ Q_orth.T
+            D_rot = torch.diag_embed(sp) + sp[:, None] * self.M @ Bt @ self.M.T * sp[None, :]
+            return QRm @ D_rot @ QRm.T + M_term + M_term.T + B_term
+        if self.scalar_B:
+            if self.log_B_tilde.numel() > 0:
+                eye = torch.eye(p, dtype=QRm.dtype, device=QRm.device)
+                B_term = torch.exp(self.log_B_tilde[0]) * (eye - Q @ Q.T)
+            else:
+                B_term = 0.
+        else:
+            Br = Q_orth @ self._B_tilde_root()
+            B_term = Br @ Br.T
+        Droot = QRm * torch.sqrt(sp)[None, :]
+        return Droot @ Droot.T + B_term
+
+    def full_likelihood(self):
+        """MultitaskGaussianLikelihood(rank=p, no global noise) whose factor is the jittered Cholesky
+        of Sigma (projected_lmc.py:1023-1074)."""
+        res = MultitaskGaussianLikelihood(num_tasks=self.n_tasks, rank=self.n_tasks, has_global_noise=False)
+        Sigma = self.full_noise_covariance()
+        res = res.to(device=Sigma.device, dtype=Sigma.dtype)
+        with torch.no_grad():
+            eps = 1e-6
+            eye = torch.eye(self.n_tasks, dtype=Sigma.dtype, device=Sigma.device)
+            while eps < self.eps:
+                L, info = torch.linalg.cholesky_ex(Sigma + eps * eye)
+                if int(info) == 0:
+                    res.task_noise_covar_factor.data = L
+                    break
+                eps *= 10
+                warnings.warn("Cholesky of the full noise covariance failed. Trying again with jitter {0} ...".format(eps))
+        return res
+
+    def B_tilde(self):
+        if self.diagonal_B:
+            return torch.diag_embed(torch.exp(self.log_B_tilde))
+        r = self._B_tilde_root()
+        return r @ r.T
+
+    # ------------------------------------------------------------------------------------ forward
+    def forward(self, x):
+        """Prior of the latent processes only (projected_lmc.py:1088-1091)."""
+        return MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    def _latent_posterior(self, x, full_cov=False):
+        tx = self.train_inputs[0]
+        lazy = self.covar_module(tx)
+        ytil = self.project_data(self.train_y).detach()
+        ids = self.latent_ids
+        ell, osc, noise = lazy.ell.detach(), lazy.oscale, self.projected_noise().detach().to(lazy.ell.dtype)
+        osc = None if osc is None else osc.detach()
+        if ids is not None:
+            ell, noise, ytil = ell[ids], noise[ids], ytil[ids]
+            osc = None if osc is None else osc[ids]
+        return _engine.exact_posterior(lazy.kind, lazy.x1, ell, osc, noise, ytil, self.covar_module.select(x),
+                                       full_cov=full_cov)
+
+    def compute_latent_distrib(self, x, full_cov=True, **kwargs):
+        """Posterior of the latent processes at x, mean (q x n) (projected_lmc.py:1093-1106)."""
+        if self.training:
+            return self.forward(x)
+        mean, v = self._latent_posterior(x, full_cov=full_cov)
+        return MultivariateNormal(mean, v if full_cov else torch.diag_embed(v))
+
+    def _posterior(self, x, full_cov=False, **kwargs):
+        """Task-space posterior: mean = latent_mean^T H^T, covariance = sum_i S_i (x) h_i h_i^T + eps I
+        (projected_lmc.py:1133-1155).  By default only the latent variances are formed (what
+        `.variance` / `.confidence_region()` need); full_cov=True keeps the n* x n* latent blocks.
+        With latent sharding the partial sums are all-reduced (the one cross-latent reduction)."""
+        mean_lat, v = self._latent_posterior(x, full_cov=full_cov)
+        Ht = self.lmc_coefficients().detach()
+        if self.latent_ids is not None:
+            Ht_loc = Ht[self.latent_ids]
+            mean = mean_lat.T @ Ht_loc
+            var = (v if not full_cov else torch.diagonal(v, dim1=-2, dim2=-1)).T @ (Ht_loc * Ht_loc)
+            from . import parallel
+            buf = torch.stack([mean, var])
+            parallel.all_reduce_sum(buf)
+            mean, var = buf[0], buf[1] + self.eps
+            return MultitaskMultivariateNormal(mean, _DiagonalTaskCovariance(var))
+        mean = mean_lat.T @ Ht
+        cov = KroneckerSumCovariance(Ht, cov=v if full_cov else None, var=None if full_cov else v, eps=self.eps)
+        return MultitaskMultivariateNormal(mean, cov)
+
+
+class _DiagonalTaskCovariance:
+    """Marginal task variances only (sharded prediction path)."""
+
+    def __init__(self, var, task_noise=None):
+        self.var, self.task_noise = var, task_noise
+
+    def add_task_noise(self, Sigma):
+        return _DiagonalTaskCovariance(self.var, Sigma if self.task_noise is None else self.task_noise + Sigma)
+
+    def diagonal(self, *a, **k):
+        v = self.var
+        if self.task_noise is not None:
+            v = v + torch.diagonal(self.task_noise)[None, :]
+        return v.reshape(-1)
+
+    def evaluate(self):
+        raise RuntimeError("only marginal variances are available on the sharded prediction path")
+
+
+class ProjectedLMCmll(ExactMarginalLogLikelihood):
+    """Loss of the ProjectedGPModel (projected_lmc.py:1158-1241): sum of the q latent exact-GP
+    log-likelihoods of the projected data (HIP engine) / n, plus the projection terms."""
+
+    def __init__(self, latent_likelihood, model):
+        if not isinstance(latent_likelihood, _GaussianLikelihoodBase):
+            raise RuntimeError("Likelihood must be Gaussian for exact inference")
+        super().__init__(latent_likelihood, model)
+        self.previous_lat = None
+
+    def forward(self, latent_function_dist, target, inputs=None, *params):
+        if not isinstance(latent_function_dist, MultivariateNormal):
+            raise RuntimeError("ExactMarginalLogLikelihood can only operate on Gaussian random variables")
+        model = self.model
+        num_data = latent_function_dist.event_shape.numel()
+        proj_target = model.project_data(target)                         # q x n
+        latent_output = self.likelihood(latent_function_dist, *params)
+        ids = model.latent_ids
+        if ids is None:
+            latent_res = latent_output.log_prob(proj_target)
+        else:                                                            # this rank's latents only
+            c = latent_output.lazy_covariance_matrix
+            osc = None if c.oscale is None else c.oscale[ids]
+            latent_res = _engine.exact_latent_log_prob(c.kind, c.x1, c.ell[ids], osc, c.noise.reshape(-1)[ids],
+                                                       proj_target[ids])
+        latent_res = self._add_other_terms(latent_res, params).sum() / num_data
+
+        p, q = model.n_tasks, model.n_latents
+        self.proj_term_list = [0] * 3
+        Q, R, Q_orth = model.lmc_coefficients.QR()
+        if not hasattr(model, 'M') and model.scalar_B:
+            if model.log_B_tilde.numel() > 0:
+                lb = model.log_B_tilde
+                root_diag = lb / 2
+                self.proj_term_list[1] = -0.5 * torch.exp(-lb[0]) * (model.Y_squared_norm - (target @ Q).pow(2).sum()) / num_data
+            else:
+                self.proj_term_list[1] = 0.
+                root_diag = torch.zeros(1, dtype=target.dtype, device=target.device)
+        else:
+            rot = target @ Q_orth                                        # n x (p-q)
+            if model.diagonal_B:
+                root_diag = model.log_B_tilde / 2
+                # the reference forms the n x n matrix rot B^-1 rot^T and takes its trace (:1224,:1230);
+                # the same number is the weighted squared Frobenius norm, O(n (p-q))
+                self.proj_term_list[1] = -0.5 * (rot.pow(2) * torch.exp(-model.log_B_tilde)[None, :]).sum() / num_data
+            else:
+                Bc = model.B_tilde_inv_chol
+                root_diag = -torch.log(torch.diagonal(Bc))
+                self.proj_term_list[1] = -0.5 * (rot @ Bc).pow(2).sum() / num_data
+        self.proj_term_list[0] = -0.5 * 2 * torch.sum(root_diag)
+        if model.lmc_coefficients.bulk:
+            self.proj_term_list[2] = -0.5 * torch.log(torch.diagonal(R) ** 2).sum()
+        else:
+            self.proj_term_list[2] = -0.5 * 2 * torch.diagonal(model.lmc_coefficients.parametrizations.R.original).sum()
+        projection_term = sum(self.proj_term_list) - 0.5 * (p - q) * math.log(2 * math.pi)
+        if ids is not None and model.latent_shard[0] != 0:
+            # replicated terms are counted once (on rank 0) so that the all-reduced sum is the loss
+            projection_term = projection_term * 0.0
+        return latent_res + projection_term

@@ -1,0 +1,160 @@
+"""GPU parity of the model-level API (ProjectedGPModel + ProjectedLMCmll, ExactGPModel + ExactMLL)
+against the CPU oracle: loss, gradients w.r.t. every parameter, and eval-mode predictions."""
+import warnings
+
+import pytest
+import torch
+
+from oracle import projected as pj
+from oracle import lmc_dense as ld
+from oracle import gp_math as gm
+from _bridge import oracle_params, param_map, perturb_
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {
+    "PLMC": dict(BDN=False, diagonal_B=False, scalar_B=False),            # experiments.py:197-200
+    "PLMC_diagB": dict(BDN=False, diagonal_B=True, scalar_B=False),
+    "BDN_fullB": dict(BDN=True, diagonal_B=False, scalar_B=False),
+    "oilmm": dict(BDN=True, diagonal_B=True, scalar_B=True, diagonal_R=True),   # experiments.py:203-207
+    "PLMC_fast": dict(BDN=True, diagonal_B=True, scalar_B=True),          # experiments.py:211-215
+}
+DEV = "cuda:0"
+
+
+def _data(n, d, p, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    X = 2 * torch.rand(n, d, generator=g, dtype=torch.float64) - 1
+    Y = torch.randn(n, p, generator=g, dtype=torch.float64)
+    return X, Y
+
+
+def _model(plmc, X, Y, q, kernel, **kw):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return plmc.ProjectedGPModel(X, Y, Y.shape[1], q, mean_type=plmc.ZeroMean, kernel_type=kernel, **kw)
+
+
+@pytest.fixture(scope="module")
+def plmc():
+    import projectedlmc
+    assert torch.cuda.is_available()
+    return projectedlmc
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+@pytest.mark.parametrize("kernel,oscale", [("MaternKernel", False), ("RBFKernel", True)])
+def test_training_loss_and_all_gradients(plmc, name, kernel, oscale):
+    n, d, p, q = 333, 3, 6, 2
+    X, Y = _data(n, d, p, seed=11)
+    torch.manual_seed(5)
+    m = _model(plmc, X, Y, q, getattr(plmc, kernel), init_lmc_coeffs=True, outputscales=oscale, **VARIANTS[name])
+    m = perturb_(m.double())
+    P = oracle_params(m)
+    for k in pj.tensor_keys(P):
+        P[k].requires_grad_(True)
+    ref = -pj.projected_mll(P, X, Y)
+    ref.backward()
+
+    m = m.to(DEV)
+    Xd, Yd = X.to(DEV), Y.to(DEV)
+    m.train()
+    m.likelihood.train()
+    mll = plmc.ProjectedLMCmll(m.likelihood, m)
+    loss = -mll(m(Xd), Yd)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) < 1e-9 * abs(float(ref)), (float(loss), float(ref))
+    pm = param_map(m)
+    checked = 0
+    for pname, prm in m.named_parameters():
+        g_ref = P[pm[pname]].grad
+        assert prm.grad is not None, pname
+        assert torch.allclose(prm.grad.cpu(), g_ref, rtol=2e-6, atol=1e-8), (pname, prm.grad.cpu(), g_ref)
+        checked += 1
+    assert checked >= 4
+    # the stored projection terms are those of the reference's proj_term_list (:1206)
+    terms, _ = pj.projection_terms(P, Y)
+    for a, b in zip(mll.proj_term_list, terms):
+        assert abs(float(a) - float(b)) < 1e-9 * max(1.0, abs(float(b)))
+
+
+@pytest.mark.parametrize("name", ["PLMC", "PLMC_fast"])
+def test_eval_mode_task_posterior(plmc, name):
+    n, d, p, q, ns = 200, 2, 5, 2, 64
+    X, Y = _data(n, d, p, seed=2)
+    Xs = 2 * torch.rand(ns, d, dtype=torch.float64) - 1
+    torch.manual_seed(1)
+    m = perturb_(_model(plmc, X, Y, q, plmc.MaternKernel, init_lmc_coeffs=True, **VARIANTS[name]).double())
+    P = oracle_params(m)
+    mean_ref, cov_ref = pj.task_posterior(P, X, Y, Xs)
+    _, var_obs_ref = pj.observed_posterior(P, X, Y, Xs)
+    m = m.to(DEV)
+    m.eval()
+    m.likelihood.eval()
+    with torch.no_grad():
+        full_likelihood = m.full_likelihood()
+        dist = m(Xs.to(DEV))
+        obs = full_likelihood(dist)                         # experiments.py:317-321
+        assert dist.mean.shape == (ns, p)
+        assert torch.allclose(dist.mean.cpu(), mean_ref, rtol=1e-8, atol=1e-10)
+        assert torch.allclose(dist.variance.cpu(), torch.diagonal(cov_ref).reshape(ns, p), rtol=1e-7, atol=1e-10)
+        assert torch.allclose(obs.variance.cpu(), var_obs_ref, rtol=1e-7, atol=1e-10)
+        lo, hi = obs.confidence_region()
+        assert torch.allclose((hi - lo).cpu(), 4 * var_obs_ref.sqrt(), rtol=1e-7)
+        full = m(Xs.to(DEV), full_cov=True)
+        assert torch.allclose(full.covariance_matrix.cpu(), cov_ref, rtol=1e-7, atol=1e-9)
+        lat = m.compute_latent_distrib(Xs.to(DEV))
+        assert lat.mean.shape == (q, ns)
+
+
+def test_exact_gp_single_output_config1(plmc):
+    """BASELINE config 1: ExactGPModel single-output RBF, n=512, d=4 (README.md:33-58 usage)."""
+    n, d = 512, 4
+    X, Y = _data(n, d, 1, seed=4)
+    y = Y[:, 0].contiguous()
+    lik = plmc.GaussianLikelihood()
+    model = plmc.ExactGPModel(X, y, lik, mean_type=plmc.ConstantMean, kernel_type=plmc.RBFKernel).double()
+    lik = lik.double()
+    with torch.no_grad():
+        model.mean_module.raw_constant.fill_(0.3)
+        model.covar_module.raw_lengthscale.copy_(torch.tensor([[[0.2, -0.3, 0.5, 0.1]]], dtype=torch.float64))
+    raw_ls = model.covar_module.raw_lengthscale.detach().clone().requires_grad_()
+    raw_nz = lik.noise_covar.raw_noise.detach().clone().requires_grad_()
+    c = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)
+    ref = ld.exact_gp_mll("rbf", X, y, gm.softplus(raw_ls).reshape(1, d), gm.softplus(raw_nz).reshape(1) + 1e-4, c)
+    ref.backward()
+
+    model, lik = model.to(DEV), lik.to(DEV)
+    model.train(); lik.train()
+    mll = plmc.ExactMarginalLogLikelihood(lik, model)
+    out = mll(model(X.to(DEV)), y.to(DEV))
+    out.sum().backward()
+    assert abs(float(out.sum()) - float(ref)) < 1e-10 * abs(float(ref))
+    assert torch.allclose(model.covar_module.raw_lengthscale.grad.cpu(), raw_ls.grad, rtol=1e-6, atol=1e-9)
+    assert torch.allclose(lik.noise_covar.raw_noise.grad.cpu(), raw_nz.grad, rtol=1e-6, atol=1e-9)
+    assert torch.allclose(model.mean_module.raw_constant.grad.cpu(), c.grad, rtol=1e-6, atol=1e-9)
+    # prediction
+    Xs = 2 * torch.rand(50, d, dtype=torch.float64) - 1
+    mu, cov = gm.exact_gp_posterior("rbf", X, gm.softplus(raw_ls.detach()).reshape(1, d),
+                                    gm.softplus(raw_nz.detach()).reshape(1) + 1e-4, y[None], Xs, mean=torch.tensor([0.3], dtype=torch.float64))
+    model.eval(); lik.eval()
+    with torch.no_grad():
+        pred = model(Xs.to(DEV))
+    assert torch.allclose(pred.mean.cpu(), mu[0], rtol=1e-8, atol=1e-10)
+    assert torch.allclose(pred.variance.cpu(), torch.diagonal(cov[0]), rtol=1e-7, atol=1e-10)
+    assert model.lscales().shape == (d,)
+
+
+def test_fp32_projected_step_meets_the_1e4_target(plmc):
+    """BASELINE target: fp32 log-likelihood within 1e-4 relative of the fp64 oracle."""
+    n, d, p, q = 1024, 8, 8, 4
+    X, Y = _data(n, d, p, seed=9)
+    torch.manual_seed(0)
+    m = _model(plmc, X.float(), Y.float(), q, plmc.MaternKernel, init_lmc_coeffs=True, **VARIANTS["PLMC_fast"])
+    P = oracle_params(m)
+    ref = float(pj.projected_mll(P, X, Y))
+    m = m.to(DEV)
+    m.train()
+    mll = plmc.ProjectedLMCmll(m.likelihood, m)
+    val = float(mll(m(X.float().to(DEV)), Y.float().to(DEV)))
+    assert abs(val - ref) < 1e-4 * abs(ref), (val, ref)

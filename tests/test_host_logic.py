@@ -1,0 +1,146 @@
+"""CPU tests of the host-side mirror (no GPU, no compute calls into the HIP library):
+the p x q projection algebra against the oracle, constructor semantics / error behaviour of the
+reference, state-dict names, the C-ABI export list, and the loud failure without a GPU."""
+import ctypes
+import os
+import re
+import warnings
+
+import pytest
+import torch
+
+import projectedlmc as plmc
+from oracle import projected as pj
+from _bridge import oracle_params, perturb_
+
+
+
+@pytest.fixture(autouse=True)
+def _float64_default():
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
+
+VARIANTS = {
+    "PLMC": dict(BDN=False, diagonal_B=False, scalar_B=False),
+    "PLMC_diagB": dict(BDN=False, diagonal_B=True, scalar_B=False),
+    "BDN_fullB": dict(BDN=True, diagonal_B=False, scalar_B=False),
+    "BDN_diagB": dict(BDN=True, diagonal_B=True, scalar_B=False),
+    "PLMC_fast": dict(BDN=True, diagonal_B=True, scalar_B=True),
+}
+
+
+def _data(n=60, d=3, p=6, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return 2 * torch.rand(n, d, generator=g) - 1, torch.randn(n, p, generator=g)
+
+
+def _model(X, Y, q, **kw):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return plmc.ProjectedGPModel(X, Y, Y.shape[1], q, mean_type=plmc.ZeroMean, kernel_type=plmc.MaternKernel, **kw)
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+@pytest.mark.parametrize("init", [False, True])
+def test_projection_algebra_matches_oracle(name, init):
+    X, Y = _data()
+    torch.manual_seed(3)
+    m = perturb_(_model(X, Y, 2, init_lmc_coeffs=init, **VARIANTS[name]))
+    P = oracle_params(m)
+    assert torch.allclose(m.project_data(Y), pj.project_data(P, Y), atol=1e-12)
+    assert torch.allclose(m.projection_matrix(), pj.projection_matrix(P), atol=1e-12)
+    assert torch.allclose(m.full_noise_covariance(), pj.full_noise_covariance(P), atol=1e-12)
+    assert torch.allclose(m.lmc_coefficients(), pj.lmc_coefficients(P), atol=1e-14)
+    assert torch.allclose(m.B_tilde(), pj.B_tilde(P), atol=1e-12)
+    assert torch.allclose(m.projected_noise(), pj.projected_noise(P), atol=1e-14)
+    fl = m.full_likelihood()
+    assert torch.allclose(fl.task_noise_covar_factor.data, pj.full_noise_factor(P), atol=1e-10)
+    assert not hasattr(fl, "noise")                      # has_global_noise=False (experiments.py:323)
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_initial_parameters_match_oracle_init(name):
+    """Same initial values as projected_lmc.py:916-993 (SVD init path is deterministic)."""
+    X, Y = _data(n=80, p=5)
+    m = _model(X, Y, 3, init_lmc_coeffs=True, **VARIANTS[name])
+    P0 = pj.init_params(X, Y, 3, kind="matern", init_lmc_coeffs=True, **VARIANTS[name])
+    P = oracle_params(m)
+    # H is defined up to the sign of each singular vector; compare the sign-invariant products
+    assert torch.allclose(P["H"] @ P["H"].T, P0["H"] @ P0["H"].T, atol=1e-10)
+    assert torch.allclose(pj.full_noise_covariance(P), pj.full_noise_covariance(P0), atol=1e-10)
+    for k in ("raw_noise", "raw_lengthscale", "log_B_tilde", "B_tilde_inv_chol_raw", "M"):
+        if k in P0:
+            assert torch.allclose(P[k], P0[k], atol=1e-12), k
+
+
+def test_svd_init_matches_sklearn_convention():
+    """init_lmc_coefficients (projected_lmc.py:183-201): same numbers as sklearn's randomized_svd
+    whenever its range finder is exact (q + 10 >= p), including the svd_flip sign convention."""
+    X, Y = _data(n=100, p=7)
+    for q in (2, 5, 7):
+        ours = plmc.init_lmc_coefficients(Y, q)
+        ref = pj.svd_init(Y, q)
+        assert torch.allclose(ours, ref, atol=1e-9), q
+        U, S = plmc.init_lmc_coefficients(Y, q, QR_form=True)
+        Ur, Sr = pj.svd_init(Y, q, QR_form=True)
+        assert torch.allclose(U, Ur, atol=1e-9) and torch.allclose(S, Sr, atol=1e-9)
+
+
+def test_constructor_errors_and_warnings():
+    X, Y = _data()
+    with pytest.warns(UserWarning, match="dimension of the likelihood"):
+        plmc.ProjectedGPModel(X, Y, 6, 2, mean_type=plmc.ZeroMean)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(ValueError, match="non-zero output-wise means"):
+            plmc.ProjectedGPModel(X, Y, 6, 2)                      # default ConstantMean is rejected (:927-928)
+    with pytest.raises(ValueError, match="Wrong dimensions for Q_plus"):
+        plmc.LMCMixingMatrix(torch.eye(5)[:, :3], torch.eye(2))
+    with pytest.raises(RuntimeError, match="Likelihood must be Gaussian"):
+        plmc.ProjectedLMCmll(torch.nn.Identity(), None)
+    with pytest.raises(ValueError, match="prior width"):
+        plmc.handle_covar_(plmc.RBFKernel, 3, prior_scales=torch.ones(3))
+
+
+def test_state_dict_names_are_the_reference_ones():
+    X, Y = _data()
+    m = _model(X, Y, 2, BDN=True, scalar_B=True, diagonal_B=True, outputscales=True)
+    keys = set(m.state_dict())
+    assert {"likelihood.noise_covar.raw_noise", "covar_module.base_kernel.raw_lengthscale",
+            "covar_module.raw_outputscale", "lmc_coefficients.H", "parametrizations.log_B_tilde.original",
+            "train_y", "Y_squared_norm"} <= keys
+    m2 = _model(X, Y, 2, BDN=False, bulk=False)
+    keys2 = set(m2.state_dict())
+    assert {"lmc_coefficients.parametrizations.Q_plus.original", "lmc_coefficients.parametrizations.R.original",
+            "parametrizations.B_tilde_inv_chol.original", "M"} <= keys2
+    assert m.covar_module.base_kernel.raw_lengthscale.shape == (2, 1, 3)
+    assert m.likelihood.noise_covar.raw_noise.shape == (2, 1)
+    assert abs(float(m.likelihood.noise[0]) - (0.6931471805599453 + 1.2340980408667956e-4)) < 1e-12
+
+
+def test_train_mode_requires_training_inputs_and_hot_path_needs_gpu():
+    X, Y = _data()
+    m = _model(X, Y, 2)
+    m.train()
+    with pytest.raises(RuntimeError, match="train on the training inputs"):
+        m(X[:10])
+    out = m(X)
+    assert out.mean.shape == (2, 60) and out.lazy_covariance_matrix.shape == (2, 60, 60)
+    mll = plmc.ProjectedLMCmll(m.likelihood, m)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mll(out, Y)
+
+
+def test_c_abi_exports_every_declared_symbol(repo_root):
+    from projectedlmc import _hip
+    header = open(os.path.join(repo_root, "include", "plmc.h")).read()
+    declared = set(re.findall(r"\b(plmc_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_hip.exported_symbols())
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.plmc_block() == 128 and lib.plmc_version() >= 1
+    lib.plmc_pad.restype, lib.plmc_pad.argtypes = ctypes.c_int64, [ctypes.c_int64]
+    assert lib.plmc_pad(1) == 128 and lib.plmc_pad(128) == 128 and lib.plmc_pad(8193) == 8320

@@ -9,7 +9,14 @@ from oracle import gp_math as gm
 from oracle import projected as pj
 from oracle import lmc_dense as ld
 
-torch.set_default_dtype(torch.float64)
+
+
+@pytest.fixture(autouse=True)
+def _float64_default():
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
 
 
 def _data(n=40, d=3, p=5, seed=0):
