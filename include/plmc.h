@@ -14,15 +14,19 @@
  *   - dtype by suffix: _f32 / _f64.  Everything row-major.
  *   - Blocked algorithms use NB = 128 (plmc_block()).  n_pad = plmc_pad(n) = n rounded up to NB.
  *   - "Factor buffer" A, one per latent GP (batch stride strideA elements):
- *        n_pad rows x lda columns, lda = n_pad + naug_pad (naug_pad = plmc_pad(naug), >= 0).
- *        columns [0, n_pad)       : UPPER triangle holds Khat = K + noise*I, then its factor U
- *                                   (Khat = U^T U); padded rows/cols hold the identity.
- *        columns [n_pad, lda)     : augmented right-hand sides (targets, cross-covariances);
- *                                   potrf turns each column c into U^-T c (forward solve for free).
+ *        n_pad rows x lda columns, lda >= n_pad + naug_pad (+ n_pad when the inverse factor is
+ *        requested), naug_pad = plmc_pad(naug) >= 0, lda a multiple of NB.
+ *        columns [0, n_pad)               : UPPER triangle holds Khat = K + noise*I, then its factor U
+ *                                           (Khat = U^T U); padded rows/cols hold the identity.
+ *        columns [n_pad, n_pad+naug_pad)  : augmented right-hand sides (targets, cross-covariances);
+ *                                           potrf turns each column c into U^-T c (forward solve for free).
+ *        columns [n_pad+naug_pad, +n_pad) : (with_inverse) W = U^-T, LOWER triangle, produced by the same
+ *                                           sweep (explicit zeros above the diagonal inside diagonal
+ *                                           blocks; blocks strictly above the diagonal are never touched).
  *     The strictly lower triangle of the square part is never read.
  *   - Vd: per latent (n_pad/NB) blocks of NB x NB: inverses of the diagonal blocks of U (upper).
- *   - W : per latent n_pad x ldw (ldw >= n_pad), LOWER triangle = U^-T (explicit zeros above the
- *         diagonal inside diagonal blocks; blocks strictly above the diagonal are never touched).
+ *   - "W, ldw, strideW" arguments below: pointer to the first W column of latent 0 inside the factor
+ *     buffer (A + n_pad + naug_pad), ldw = lda, strideW = strideA -- or any buffer of that layout.
  *   - kernel kinds: PLMC_RBF, PLMC_MATERN12, PLMC_MATERN32, PLMC_MATERN52.
  */
 #ifndef PLMC_H
@@ -60,13 +64,13 @@ int plmc_assemble_f64(int kind, const double *X, int n, int d, const double *ell
 /*
  * Write right-hand sides into the augmented block: A[i][n_pad + c0 + r] = rhs[latent][r][i]
  * (rhs: q x nrhs x n, e.g. the projected targets of project_data :1014-1021, which are q x n).
- * Rows >= n and the columns of the augmented block not covered by any write are zeroed when
- * `zero_fill` != 0 (columns [n_pad, lda) are cleared before writing).
+ * Rows >= n are zero.  With clear_cols > 0 the other columns of [n_pad, n_pad + clear_cols) are
+ * zeroed too (pass naug_pad to reset the whole augmented block).
  */
 int plmc_write_rhs_f32(const float *rhs, int nrhs, int n, float *A, int64_t lda, int64_t strideA,
-                       int c0, int zero_fill, int q, void *stream);
+                       int c0, int clear_cols, int q, void *stream);
 int plmc_write_rhs_f64(const double *rhs, int nrhs, int n, double *A, int64_t lda, int64_t strideA,
-                       int c0, int zero_fill, int q, void *stream);
+                       int c0, int clear_cols, int q, void *stream);
 
 /*
  * Cross-covariance block (prediction, ProjectedGPModel.__call__ eval branch :1133-1134 -> gpytorch
@@ -87,11 +91,15 @@ int plmc_assemble_cross_f64(int kind, const double *X, int n, const double *Xs, 
  * `latent_output.log_prob(proj_target)` (:1201) / ExactMarginalLogLikelihood (experiments.py:233).
  *   logdet[latent] = log det Khat   (double), info[latent] = 0 or 1 + index of first non-PD pivot.
  * naug = number of live augmented columns (0 allowed).
+ * with_inverse != 0: also produce W = U^-T in columns [n_pad + naug_pad, n_pad + naug_pad + n_pad)
+ * (the identity rides along as further right-hand sides) -- the first half of the Khat^-1 that
+ * `loss.backward()` needs (experiments.py:270).  No initialisation of those
+ * columns is required.
  */
 int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd,
-                   double *logdet, int *info, int q, void *stream);
+                   double *logdet, int *info, int with_inverse, int q, void *stream);
 int plmc_potrf_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, double *Vd,
-                   double *logdet, int *info, int q, void *stream);
+                   double *logdet, int *info, int with_inverse, int q, void *stream);
 
 /*
  * Gather augmented column c of every latent into a contiguous vector z (q x n_pad) and return
@@ -101,13 +109,6 @@ int plmc_extract_col_f32(const float *A, int64_t n_pad, int64_t lda, int64_t str
                          float *z, double *quad, int q, void *stream);
 int plmc_extract_col_f64(const double *A, int64_t n_pad, int64_t lda, int64_t strideA, int c,
                          double *z, double *quad, int q, void *stream);
-
-/* W = U^-T (lower), blocked forward substitution on MFMA.  First third of the K^-1 needed by
- * `loss.backward()` (experiments.py:270). */
-int plmc_trtri_f32(const float *A, int64_t n_pad, int64_t lda, int64_t strideA, const float *Vd,
-                   float *W, int64_t ldw, int64_t strideW, int q, void *stream);
-int plmc_trtri_f64(const double *A, int64_t n_pad, int64_t lda, int64_t strideA, const double *Vd,
-                   double *W, int64_t ldw, int64_t strideW, int q, void *stream);
 
 /* alpha = W^T z = Khat^-1 y  (q x n_pad).  d logp / d y = -alpha. */
 int plmc_wt_matvec_f32(const float *W, int64_t n_pad, int64_t ldw, int64_t strideW, const float *z,

@@ -69,12 +69,11 @@ __global__ __launch_bounds__(NTHREADS) void k_assemble(int kind, const T *__rest
   }
 }
 
-// One thread per element of the augmented block (n_pad x naug_pad).
+// One thread per element of the first `ncols` augmented columns (n_pad x ncols).
 template <typename T>
 __global__ void k_write_rhs(const T *__restrict__ rhs, int nrhs, int n, T *__restrict__ A, int64_t n_pad,
-                            int64_t lda, int64_t strideA, int c0, int zero_fill) {
+                            int64_t lda, int64_t strideA, int c0, int64_t naug_pad, int zero_fill) {
   const int lat = blockIdx.y;
-  const int64_t naug_pad = lda - n_pad;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_pad * naug_pad) return;
   const int64_t i = idx / naug_pad;
@@ -129,16 +128,19 @@ int assemble_impl(int kind, const T *X, int n, int d, const T *ell, const T *osc
 }
 
 template <typename T>
-int write_rhs_impl(const T *rhs, int nrhs, int n, T *A, int64_t lda, int64_t strideA, int c0, int zero_fill, int q,
+int write_rhs_impl(const T *rhs, int nrhs, int n, T *A, int64_t lda, int64_t strideA, int c0, int clear_cols, int q,
                    void *stream) {
   PLMC_REQUIRE(A && (rhs || nrhs == 0), "null pointer");
   const int64_t n_pad = plmc_pad(n);
   PLMC_REQUIRE(lda > n_pad && lda % NB == 0, "no augmented block (lda must exceed n_pad)");
   PLMC_REQUIRE(c0 >= 0 && nrhs >= 0 && n_pad + c0 + nrhs <= lda, "rhs columns exceed the augmented block");
-  const int64_t tot = n_pad * (lda - n_pad);
+  PLMC_REQUIRE(clear_cols >= 0 && n_pad + clear_cols <= lda, "clear_cols exceeds the buffer");
+  const int64_t ncols = clear_cols > c0 + nrhs ? clear_cols : c0 + nrhs;
+  const int zero_fill = clear_cols > 0;
+  const int64_t tot = n_pad * ncols;
   ProfScope ps(PK_WRITE_RHS, (hipStream_t)stream, 0.0, q * (double)tot * sizeof(T));
   hipLaunchKernelGGL(k_write_rhs<T>, dim3((unsigned)((tot + 255) / 256), q), dim3(256), 0, (hipStream_t)stream, rhs,
-                     nrhs, n, A, n_pad, lda, strideA, c0, zero_fill);
+                     nrhs, n, A, n_pad, lda, strideA, c0, ncols, zero_fill);
   return launch_status(__func__);
 }
 
@@ -167,12 +169,12 @@ int plmc_assemble_f64(int kind, const double *X, int n, int d, const double *ell
   return plmc::assemble_impl<double>(kind, X, n, d, ell, oscale, noise, A, lda, strideA, q, stream);
 }
 int plmc_write_rhs_f32(const float *rhs, int nrhs, int n, float *A, int64_t lda, int64_t strideA, int c0,
-                       int zero_fill, int q, void *stream) {
-  return plmc::write_rhs_impl<float>(rhs, nrhs, n, A, lda, strideA, c0, zero_fill, q, stream);
+                       int clear_cols, int q, void *stream) {
+  return plmc::write_rhs_impl<float>(rhs, nrhs, n, A, lda, strideA, c0, clear_cols, q, stream);
 }
 int plmc_write_rhs_f64(const double *rhs, int nrhs, int n, double *A, int64_t lda, int64_t strideA, int c0,
-                       int zero_fill, int q, void *stream) {
-  return plmc::write_rhs_impl<double>(rhs, nrhs, n, A, lda, strideA, c0, zero_fill, q, stream);
+                       int clear_cols, int q, void *stream) {
+  return plmc::write_rhs_impl<double>(rhs, nrhs, n, A, lda, strideA, c0, clear_cols, q, stream);
 }
 int plmc_assemble_cross_f32(int kind, const float *X, int n, const float *Xs, int ns, int d, const float *ell,
                             const float *oscale, float *Out, int64_t ldo, int64_t strideO, int64_t col0,

@@ -71,7 +71,9 @@ __device__ __forceinline__ int tile_col(int wn, int nt, int lane) { return wn * 
 // acc += (negate ? -1 : 1) * sum_{k < K} Ag[k][0..127]^T * Bg[k][0..127]
 // Ag/Bg point at the first row of the K range and the first of the 128 columns; K % BK == 0.
 // All 256 threads must call it; ends with a barrier (LDS free for reuse on return).
-template <typename T, bool NEG>
+// REV walks the K range from its last BK-slab to its first: tiles whose ranges END together then
+// read the same operand rows at the same time (L2 sharing for the triangular products).
+template <typename T, bool NEG, bool REV = false>
 __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__ Ag, int64_t lda,
                                               const T *__restrict__ Bg, int64_t ldb, int K, T *smem) {
   using Tr = Traits<T>;
@@ -87,7 +89,9 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
   T *sB = smem + 2 * BK * LDT;
 
   vec_t ra[NCH], rb[NCH];
+  const int nkt = K / BK;
   auto gload = [&](int kt) {
+    if (REV) kt = nkt - 1 - kt;
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
       int c = tid + h * NTHREADS;
@@ -106,7 +110,6 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
     }
   };
 
-  const int nkt = K / BK;
   gload(0);
   sstore(0);
   __syncthreads();

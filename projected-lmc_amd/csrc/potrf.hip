@@ -1,161 +1,87 @@
-// potrf.hip -- blocked right-looking Cholesky Khat = U^T U on the augmented factor buffer,
-// W = U^-T by blocked forward substitution, and the two small vector kernels around them.
+// potrf.hip -- blocked right-looking Cholesky Khat = U^T U on the augmented factor buffer, with the
+// inverse factor W = U^-T produced in the same sweep, and the two small vector kernels around them.
 //
 // Replaces torch.linalg.cholesky_ex / triangular solves that gpytorch runs behind
 // `latent_output.log_prob(proj_target)` (projected_lmc.py:1201) and
-// gp.mlls.ExactMarginalLogLikelihood (experiments.py:233); SURVEY.md 8a rows a3/a4.
+// gp.mlls.ExactMarginalLogLikelihood (experiments.py:233), plus the first half of the
+// cholesky-inverse its autograd backward needs (experiments.py:270); SURVEY.md 8a rows a3/a4.
 //
-// Per block row k (NB = 128):  k_diag  (factor + invert the diagonal block in LDS)
-//                              k_panel (row panel  <- V_kk^T * panel,   MFMA)
-//                              k_trail (trailing   -= panel^T * panel,  MFMA, upper tiles + aug)
-// The augmented columns ride along, so U^-T y (and U^-T K*^T for prediction) cost nothing extra.
+// The buffer is [ Khat | rhs | I ]: everything right of the square part is "just more columns" of the
+// same elimination, so  U^-T y  (forward solve), U^-T K*^T (prediction) and W = U^-T I (inverse factor)
+// all fall out of one sweep built from two MFMA tile kernels:
+//     k_panel  : row panel  P <- V_rr^T P                      (in place, K = 128)
+//     k_update : C[i][j]  -= sum_k P[k][i] P[k][j]              (upper tiles of U, aug, live tiles of W)
+// Block rows are processed in PAIRS (two-level blocking): after block row r0 only block row r1 is
+// updated (depth 128); the large trailing update then runs once per pair with depth 256, which halves
+// the read-modify-write traffic of the trailing matrix (the HBM-bound part of the sweep).
+// Tiles of W are written (not accumulated) the first time they are touched, so W needs no memset.
 #include "api_common.hpp"
 #include "covariance.hpp"
+#include "diag_block.hpp"
 #include "../../include/plmc.h"
 
 namespace plmc {
 
-// ----------------------------------------------------------------------------------------------
-// Diagonal block: right-looking elimination of [A_kk | I] in LDS (packed triangles), giving
-// U_kk (upper) and W_kk = U_kk^-T (lower) at once.  One workgroup of 1024 threads per latent.
-// Row scaling is deferred (sInv) so each step needs a single barrier.
-constexpr int DIAG_THREADS = 1024;
+// Column-tile decoding shared by k_panel / k_update.  Tiles along grid.x are laid out as
+//   [ U block columns u0 .. m-1 | aug tiles (Taug) | W block columns 0 .. nW-1 ].
+struct ColMap {
+  int u0, nU, Taug, nW;
+  int64_t n_pad, wcol0;
+};
 
-__device__ __forceinline__ int rowU(int i) { return i * NB - (i * (i - 1)) / 2 - i; }   // U[i][j] at rowU(i)+j, j>=i
-__device__ __forceinline__ int rowL(int i) { return (i * (i + 1)) / 2; }                // W[i][c] at rowL(i)+c, c<=i
-constexpr int TRI = NB * (NB + 1) / 2;
-
+// Row panel solve P <- V_rr^T P for block row r.  grid (nU + Taug + nW, q).
 template <typename T>
-__global__ __launch_bounds__(DIAG_THREADS) void k_diag(T *__restrict__ A, int64_t lda, int64_t strideA, int kblk,
-                                                        T *__restrict__ Vd, int64_t strideV,
-                                                        double *__restrict__ logdet, int *__restrict__ info) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  T *sU = reinterpret_cast<T *>(smem_raw);
-  T *sW = sU + TRI;
-  T *sInv = sW + TRI;
-  const int lat = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int NW = DIAG_THREADS / 64;
-  T *blk = A + (int64_t)lat * strideA + (int64_t)kblk * NB * lda + (int64_t)kblk * NB;
-
-  for (int e = tid; e < NB * NB; e += DIAG_THREADS) {
-    int i = e >> 7, j = e & 127;
-    if (j >= i) sU[rowU(i) + j] = blk[(int64_t)i * lda + j];
-    if (j <= i) sW[rowL(i) + j] = (i == j) ? T(1) : T(0);
-  }
-  __syncthreads();
-
-  double lacc = 0.0;
-  int bad = 0;
-  for (int k = 0; k < NB; ++k) {
-    const T piv = sU[rowU(k) + k];
-    const bool ok = piv > T(0);
-    const T inv = ok ? T(1) / dsqrt(piv) : T(1);
-    if (tid == 0) {
-      sInv[k] = inv;
-      if (ok) lacc += log((double)piv);
-      else if (!bad) bad = kblk * NB + k + 1;
-    }
-    const int ru_k = rowU(k), rl_k = rowL(k);
-    for (int i = k + 1 + wave; i < NB; i += NW) {
-      const T uki = sU[ru_k + i] * inv;
-      const int ru_i = rowU(i), rl_i = rowL(i);
-      for (int j = i + lane; j < NB; j += 64) sU[ru_i + j] -= uki * (sU[ru_k + j] * inv);
-      for (int c = lane; c <= k; c += 64) sW[rl_i + c] -= uki * (sW[rl_k + c] * inv);
-    }
-    __syncthreads();
-  }
-  // write back: U_kk (upper part only), Vd = W_kk^T as a full block with explicit zeros below.
-  T *vd = Vd + (int64_t)lat * strideV + (int64_t)kblk * NB * NB;
-  for (int e = tid; e < NB * NB; e += DIAG_THREADS) {
-    int i = e >> 7, j = e & 127;
-    if (j >= i) {
-      blk[(int64_t)i * lda + j] = sU[rowU(i) + j] * sInv[i];
-      vd[e] = sW[rowL(j) + i] * sInv[j];          // V[i][j] = W[j][i]
-    } else {
-      vd[e] = T(0);
-    }
-  }
-  if (tid == 0) {
-    if (kblk == 0) { logdet[lat] = lacc; info[lat] = bad; }
-    else { logdet[lat] += lacc; if (bad && info[lat] == 0) info[lat] = bad; }
-  }
-}
-
-// ----------------------------------------------------------------------------------------------
-// Row panel solve: P <- V_kk^T P for the 128-row panel right of the diagonal block (and the
-// augmented block).  grid (T + Taug, q); in place (each workgroup owns a full column strip).
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_panel(T *A, int64_t n_pad, int64_t lda, int64_t strideA,
-                                                     int kblk, int Ttr, const T *__restrict__ Vd, int64_t strideV) {
+__global__ __launch_bounds__(NTHREADS) void k_panel(T *A, int64_t lda, int64_t strideA, int r, ColMap cm,
+                                                     const T *__restrict__ Vd, int64_t strideV) {
   __shared__ __align__(16) T smem[tile_smem_elems<T>()];
-  const int lat = blockIdx.y;
-  const int t = blockIdx.x;
-  const int64_t col0 = t < Ttr ? (int64_t)(kblk + 1 + t) * NB : n_pad + (int64_t)(t - Ttr) * NB;
-  T *P = A + (int64_t)lat * strideA + (int64_t)kblk * NB * lda + col0;
-  const T *V = Vd + (int64_t)lat * strideV + (int64_t)kblk * NB * NB;
+  const int lat = blockIdx.y, t = blockIdx.x;
+  int64_t col0;
+  if (t < cm.nU) col0 = (int64_t)(cm.u0 + t) * NB;
+  else if (t < cm.nU + cm.Taug) col0 = cm.n_pad + (int64_t)(t - cm.nU) * NB;
+  else col0 = cm.wcol0 + (int64_t)(t - cm.nU - cm.Taug) * NB;
+  T *P = A + (int64_t)lat * strideA + (int64_t)r * NB * lda + col0;
+  const T *V = Vd + (int64_t)lat * strideV + (int64_t)r * NB * NB;
   Acc<T> acc;
   acc.zero();
   tile_mainloop<T, false>(acc, V, NB, P, lda, NB, smem);
   tile_store<T>(acc, P, lda);
 }
 
-// Trailing update: C[i][j] -= sum_k P[k][i] P[k][j] over upper tiles of the trailing matrix and
-// the augmented block.  grid (T + Taug, T, q).
+// Rank-(128|256) update of block rows [ib0, ib0 + gridDim.y) with the panel rows of block rows
+// r_lo..r_hi:  C[i][j] -= sum_{k in panel} P[k][i] P[k][j].   grid (nU + Taug + nW, nrows, q).
+//   U columns : tiles with jb >= ib (upper), read-modify-write.
+//   aug       : read-modify-write.
+//   W column cb < r_lo : read-modify-write, full panel depth;
+//            cb == r_lo : first touch -> plain store, full depth;
+//            cb == r_hi (> r_lo): first touch, only the rows of block r_hi contribute (W[r_lo][r_hi] = 0).
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_trail(T *A, int64_t n_pad, int64_t lda, int64_t strideA,
-                                                     int kblk, int Ttr) {
-  const int bx = blockIdx.x, by = blockIdx.y, lat = blockIdx.z;
-  if (bx < Ttr && bx < by) return;
-  __shared__ __align__(16) T smem[tile_smem_elems<T>()];
-  const int ib = kblk + 1 + by;
-  const int64_t col0 = bx < Ttr ? (int64_t)(kblk + 1 + bx) * NB : n_pad + (int64_t)(bx - Ttr) * NB;
-  T *Al = A + (int64_t)lat * strideA;
-  const T *Prow = Al + (int64_t)kblk * NB * lda;
-  Acc<T> acc;
-  acc.zero();
-  tile_mainloop<T, true>(acc, Prow + (int64_t)ib * NB, lda, Prow + col0, lda, NB, smem);
-  tile_add_store<T>(acc, Al + (int64_t)ib * NB * lda + col0, lda);
-}
-
-// ----------------------------------------------------------------------------------------------
-// W diagonal blocks: W[kb+a][kb+b] = V_k[b][a] (lower, explicit zeros above).  grid (m, q).
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_wdiag(const T *__restrict__ Vd, int64_t strideV, T *__restrict__ W,
-                                                     int64_t ldw, int64_t strideW) {
-  __shared__ T s[NB][NB + 1];
-  const int k = blockIdx.x, lat = blockIdx.y;
-  const T *v = Vd + (int64_t)lat * strideV + (int64_t)k * NB * NB;
-  for (int e = threadIdx.x; e < NB * NB; e += NTHREADS) s[e >> 7][e & 127] = v[e];
-  __syncthreads();
-  T *w = W + (int64_t)lat * strideW + (int64_t)k * NB * ldw + (int64_t)k * NB;
-  for (int e = threadIdx.x; e < NB * NB; e += NTHREADS) {
-    int a = e >> 7, b = e & 127;
-    w[(int64_t)a * ldw + b] = b <= a ? s[b][a] : T(0);
+__global__ __launch_bounds__(NTHREADS) void k_update(T *A, int64_t lda, int64_t strideA, int ib0, int r_lo, int r_hi,
+                                                      ColMap cm) {
+  const int bx = blockIdx.x, ib = ib0 + blockIdx.y, lat = blockIdx.z;
+  int64_t col0;
+  int kr0 = r_lo * NB, depth = (r_hi - r_lo + 1) * NB;
+  bool first = false;
+  if (bx < cm.nU) {
+    const int jb = cm.u0 + bx;
+    if (jb < ib) return;
+    col0 = (int64_t)jb * NB;
+  } else if (bx < cm.nU + cm.Taug) {
+    col0 = cm.n_pad + (int64_t)(bx - cm.nU) * NB;
+  } else {
+    const int cb = bx - cm.nU - cm.Taug;
+    col0 = cm.wcol0 + (int64_t)cb * NB;
+    if (cb == r_lo) first = true;
+    else if (cb == r_hi) { first = true; kr0 = r_hi * NB; depth = NB; }
   }
-}
-
-// Block row k of W = U^-T (k >= 1), tiles jb < k:  S = sum_{l in [jb*NB, k*NB)} U[l][k-block]^T W[l][jb-block],
-// W[k][jb] = -V_kk^T S.  grid (k, q).  S is staged through the output tile itself.
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_trtri_row(const T *__restrict__ A, int64_t lda, int64_t strideA,
-                                                         const T *__restrict__ Vd, int64_t strideV, T *W,
-                                                         int64_t ldw, int64_t strideW, int kblk) {
   __shared__ __align__(16) T smem[tile_smem_elems<T>()];
-  const int jb = blockIdx.x, lat = blockIdx.y;
-  const T *Al = A + (int64_t)lat * strideA;
-  T *Wl = W + (int64_t)lat * strideW;
+  T *Al = A + (int64_t)lat * strideA;
+  const T *Prow = Al + (int64_t)kr0 * lda;
   Acc<T> acc;
   acc.zero();
-  tile_mainloop<T, false>(acc, Al + (int64_t)jb * NB * lda + (int64_t)kblk * NB, lda,
-                          Wl + (int64_t)jb * NB * ldw + (int64_t)jb * NB, ldw, (kblk - jb) * NB, smem);
-  T *out = Wl + (int64_t)kblk * NB * ldw + (int64_t)jb * NB;
-  tile_store<T>(acc, out, ldw);
-  __threadfence_block();
-  __syncthreads();
-  acc.zero();
-  tile_mainloop<T, true>(acc, Vd + (int64_t)lat * strideV + (int64_t)kblk * NB * NB, NB, out, ldw, NB, smem);
-  tile_store<T>(acc, out, ldw);
+  tile_mainloop<T, true>(acc, Prow + (int64_t)ib * NB, lda, Prow + col0, lda, depth, smem);
+  T *C = Al + (int64_t)ib * NB * lda + col0;
+  if (first) tile_store<T>(acc, C, lda);
+  else tile_add_store<T>(acc, C, lda);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -203,63 +129,68 @@ __global__ __launch_bounds__(NTHREADS) void k_wt_matvec(const T *__restrict__ W,
 
 // ----------------------------------------------------------------------------------------------
 template <typename T>
-int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *Vd, double *logdet, int *info, int q,
-               void *stream) {
+int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *Vd, double *logdet, int *info,
+               int with_inverse, int q, void *stream) {
   PLMC_REQUIRE(A && Vd && logdet && info, "null pointer");
   PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0 && lda % NB == 0 && lda >= n_pad, "n_pad/lda must be multiples of NB");
-  PLMC_REQUIRE(naug >= 0 && n_pad + naug <= lda, "naug exceeds the augmented block");
+  const int64_t naug_pad = plmc_pad(naug);
+  PLMC_REQUIRE(naug >= 0 && n_pad + naug_pad + (with_inverse ? n_pad : 0) <= lda,
+               "lda too small for naug (+ the n_pad columns of the inverse factor)");
   PLMC_REQUIRE(q > 0 && aligned16(A) && aligned16(Vd), "bad q or unaligned buffer");
   hipStream_t st = (hipStream_t)stream;
   const int m = (int)(n_pad / NB);
-  const int Taug = (naug + NB - 1) / NB;
+  const int Taug = (int)(naug_pad / NB);
   const int64_t strideV = (int64_t)m * NB * NB;
+  const int64_t wcol0 = n_pad + naug_pad;
   const size_t diag_smem = (2 * TRI + NB) * sizeof(T);
   static bool attr_done[2] = {false, false};
   if (!attr_done[sizeof(T) == 8]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)diag_smem);
+                              (int)diag_smem);
     attr_done[sizeof(T) == 8] = true;
   }
-  for (int k = 0; k < m; ++k) {
-    const int Ttr = m - k - 1;
-    const double nb3 = (double)NB * NB * NB, nt = (double)Ttr * NB;
-    {
-      ProfScope ps(PK_DIAG, st, q * 2.0 * nb3 / 3.0, q * 3.0 * NB * NB * sizeof(T));
-      hipLaunchKernelGGL(k_diag<T>, dim3(q), dim3(DIAG_THREADS), diag_smem, st, A, lda, strideA, k, Vd, strideV,
-                         logdet, info);
-    }
-    if (Ttr + Taug > 0) {
-      ProfScope ps(PK_PANEL, st, q * (nt + naug) * NB * NB, q * 2.0 * (nt + naug) * NB * sizeof(T));
-      hipLaunchKernelGGL(k_panel<T>, dim3(Ttr + Taug, q), dim3(NTHREADS), 0, st, A, n_pad, lda, strideA, k, Ttr, Vd,
-                         strideV);
-    }
-    if (Ttr > 0) {
-      ProfScope ps(PK_TRAIL, st, q * (nt * nt * NB + 2.0 * nt * naug * NB),
-                   q * 2.0 * (nt * nt / 2 + nt * naug) * sizeof(T));
-      hipLaunchKernelGGL(k_trail<T>, dim3(Ttr + Taug, Ttr, q), dim3(NTHREADS), 0, st, A, n_pad, lda, strideA, k, Ttr);
-    }
-  }
-  return launch_status(__func__);
-}
+  const double nb = (double)NB, nb3 = nb * nb * nb, esz = sizeof(T);
 
-template <typename T>
-int trtri_impl(const T *A, int64_t n_pad, int64_t lda, int64_t strideA, const T *Vd, T *W, int64_t ldw,
-               int64_t strideW, int q, void *stream) {
-  PLMC_REQUIRE(A && Vd && W, "null pointer");
-  PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0 && lda % NB == 0 && ldw % NB == 0 && ldw >= n_pad, "bad leading dims");
-  PLMC_REQUIRE(q > 0 && aligned16(A) && aligned16(W) && aligned16(Vd), "bad q or unaligned buffer");
-  hipStream_t st = (hipStream_t)stream;
-  const int m = (int)(n_pad / NB);
-  const int64_t strideV = (int64_t)m * NB * NB;
-  {
-    ProfScope ps(PK_WDIAG, st, 0.0, q * 2.0 * m * NB * NB * sizeof(T));
-    hipLaunchKernelGGL(k_wdiag<T>, dim3(m, q), dim3(NTHREADS), 0, st, Vd, strideV, W, ldw, strideW);
-  }
-  for (int k = 1; k < m; ++k) {
-    const double kn = (double)k * NB;
-    ProfScope ps(PK_TRTRI, st, q * (NB * kn * kn + (double)NB * NB * kn), q * (kn * kn / 2 + 2.0 * kn * NB) * sizeof(T));
-    hipLaunchKernelGGL(k_trtri_row<T>, dim3(k, q), dim3(NTHREADS), 0, st, A, lda, strideA, Vd, strideV, W, ldw,
-                       strideW, k);
+  auto diag = [&](int r) {
+    ProfScope ps(PK_DIAG, st, q * (2.0 / 3.0) * nb3, q * 3.0 * nb * nb * esz);
+    T *wout = with_inverse ? A + (int64_t)r * NB * lda + wcol0 + (int64_t)r * NB : (T *)nullptr;
+    hipLaunchKernelGGL(k_diag<T>, dim3(q), dim3(NTHREADS), diag_smem, st, A, lda, strideA, r, Vd, strideV, wout, lda,
+                       strideA, logdet, info);
+  };
+  auto panel = [&](int r) {
+    ColMap cm{r + 1, m - 1 - r, Taug, with_inverse ? r : 0, n_pad, wcol0};
+    const int nt = cm.nU + cm.Taug + cm.nW;
+    if (nt == 0) return;
+    // algorithmic: triangular solve of nt*NB columns with a 128 x 128 factor = nb^2 flops per column
+    ProfScope ps(PK_PANEL, st, q * (double)nt * nb3, q * 2.0 * nt * nb * nb * esz);
+    hipLaunchKernelGGL(k_panel<T>, dim3(nt, q), dim3(NTHREADS), 0, st, A, lda, strideA, r, cm, Vd, strideV);
+  };
+  auto update = [&](int ib0, int nrows, int r_lo, int r_hi) {
+    if (nrows <= 0) return;
+    ColMap cm{ib0, m - ib0, Taug, with_inverse ? r_hi + 1 : 0, n_pad, wcol0};
+    const double depth = (r_hi - r_lo + 1) * nb;
+    // algorithmic flops: symmetric rank-k update of the nrows block rows (upper tiles only) + rectangular parts
+    const double nr = (double)nrows;
+    const double tilesU = nr * (cm.nU) - nr * (nr - 1) / 2.0;                   // tiles jb >= ib
+    const double flopsU = 2.0 * nb * nb * depth * (tilesU - nr / 2.0);           // diagonal tiles count half
+    const double tilesW = nr * cm.nW, tilesA = nr * Taug;
+    const double flopsR = 2.0 * nb * nb * (depth * (tilesA + tilesW) - (with_inverse && r_hi > r_lo ? nb * nr : 0.0));
+    const double bytes = (2.0 * (tilesU + tilesA + tilesW) - (with_inverse ? nr * (r_hi - r_lo + 1) : 0.0)) * nb * nb * esz;
+    ProfScope ps(PK_TRAIL, st, q * (flopsU + flopsR), q * bytes);
+    hipLaunchKernelGGL(k_update<T>, dim3(cm.nU + cm.Taug + cm.nW, nrows, q), dim3(NTHREADS), 0, st, A, lda, strideA,
+                       ib0, r_lo, r_hi, cm);
+  };
+
+  for (int r0 = 0; r0 < m; r0 += 2) {
+    const int r1 = r0 + 1;
+    diag(r0);
+    panel(r0);
+    if (r1 < m) {
+      update(r1, 1, r0, r0);
+      diag(r1);
+      panel(r1);
+      update(r1 + 1, m - r1 - 1, r0, r1);
+    }
   }
   return launch_status(__func__);
 }
@@ -290,20 +221,12 @@ int wt_matvec_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, cons
 
 extern "C" {
 int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet,
-                   int *info, int q, void *stream) {
-  return plmc::potrf_impl<float>(A, n_pad, lda, naug, strideA, Vd, logdet, info, q, stream);
+                   int *info, int with_inverse, int q, void *stream) {
+  return plmc::potrf_impl<float>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, stream);
 }
 int plmc_potrf_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, double *Vd, double *logdet,
-                   int *info, int q, void *stream) {
-  return plmc::potrf_impl<double>(A, n_pad, lda, naug, strideA, Vd, logdet, info, q, stream);
-}
-int plmc_trtri_f32(const float *A, int64_t n_pad, int64_t lda, int64_t strideA, const float *Vd, float *W,
-                   int64_t ldw, int64_t strideW, int q, void *stream) {
-  return plmc::trtri_impl<float>(A, n_pad, lda, strideA, Vd, W, ldw, strideW, q, stream);
-}
-int plmc_trtri_f64(const double *A, int64_t n_pad, int64_t lda, int64_t strideA, const double *Vd, double *W,
-                   int64_t ldw, int64_t strideW, int q, void *stream) {
-  return plmc::trtri_impl<double>(A, n_pad, lda, strideA, Vd, W, ldw, strideW, q, stream);
+                   int *info, int with_inverse, int q, void *stream) {
+  return plmc::potrf_impl<double>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, stream);
 }
 int plmc_extract_col_f32(const float *A, int64_t n_pad, int64_t lda, int64_t strideA, int c, float *z, double *quad,
                          int q, void *stream) {

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kinv_grad(int kind, const T *__res
   const T *Wl = W + (int64_t)lat * strideW + (int64_t)jb * NB * ldw;
   Acc<T> acc;
   acc.zero();
-  tile_mainloop<T, false>(acc, Wl + (int64_t)ib * NB, ldw, Wl + (int64_t)jb * NB, ldw, (int)(n_pad - (int64_t)jb * NB),
+  tile_mainloop<T, false, true>(acc, Wl + (int64_t)ib * NB, ldw, Wl + (int64_t)jb * NB, ldw, (int)(n_pad - (int64_t)jb * NB),
                           smem);
 
   // ---- epilogue: stage scaled inputs u = x / ell and alpha for the tile's rows and columns
@@ -60,7 +60,10 @@ __global__ __launch_bounds__(NTHREADS) void k_kinv_grad(int kind, const T *__res
   for (int k = 0; k < DCAP; ++k) g[k] = 0.0;
   double g_noise = 0.0, g_os = 0.0;
 
-#pragma unroll 1
+  // mt / nt are unrolled (static accumulator indices); the register r inside an MFMA tile is picked
+  // with a select chain -- a runtime-indexed accumulator would be demoted to scratch memory, and a
+  // kernel that needs scratch loses most of its occupancy.
+#pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(NTHREADS) void k_kinv_grad(int kind, const T *__res
       for (int nt = 0; nt < 4; ++nt) {
         const int col = tile_col(wn, nt, lane);
         const int gj = jb * NB + col;
-        const T kin = acc.v[mt][nt][r];
+        const auto &av = acc.v[mt][nt];
+        const T kin = r == 0 ? av[0] : (r == 1 ? av[1] : (r == 2 ? av[2] : av[3]));
         if (Kinv && gj >= gi) Kinv[(int64_t)lat * strideK + (int64_t)gi * ldk + gj] = kin;
         if (kinv_diag && gi == gj) kinv_diag[(int64_t)lat * n_pad + gi] = kin;
         if (gi < n && gj < n && gj >= gi) {

@@ -21,13 +21,17 @@ class Workspace:
     """Caller-owned device buffers for q latent GPs on n points with naug augmented columns.
     Layout documented in include/plmc.h."""
 
-    def __init__(self, n, q, naug, dtype, device, need_grad=True):
+    def __init__(self, n, q, naug, dtype, device, with_inverse=True):
         L = _hip.lib()
         self.n, self.q, self.naug, self.dtype, self.device = n, q, naug, dtype, device
+        self.with_inverse = bool(with_inverse)
         self.NB = L.cdll.plmc_block()
         self.n_pad = int(L.cdll.plmc_pad(n))
         self.naug_pad = int(L.cdll.plmc_pad(naug)) if naug > 0 else 0
-        self.lda = self.n_pad + self.naug_pad
+        self.wcol0 = self.n_pad + self.naug_pad
+        self.lda = self.wcol0 + (self.n_pad if with_inverse else 0)
+        if (self.lda // self.NB) % 2 == 0:
+            self.lda += self.NB          # odd number of blocks per row: keeps the row stride off a power of two
         self.strideA = self.n_pad * self.lda
         self.m = self.n_pad // self.NB
         self.A = torch.empty(q, self.n_pad, self.lda, dtype=dtype, device=device)
@@ -37,33 +41,26 @@ class Workspace:
         self.info = torch.empty(q, dtype=torch.int32, device=device)
         self.z = torch.empty(q, self.n_pad, dtype=dtype, device=device)
         self.W = self.alpha = self.partials = None
-        if need_grad:
-            self.ensure_grad_buffers()
-
-    def ensure_grad_buffers(self):
-        if self.W is None:
-            L = _hip.lib()
-            self.ldw = self.n_pad
-            self.strideW = self.n_pad * self.ldw
-            self.W = torch.empty(self.q, self.n_pad, self.ldw, dtype=self.dtype, device=self.device)
-            self.alpha = torch.empty(self.q, self.n_pad, dtype=self.dtype, device=self.device)
-            nbytes = int(L.cdll.plmc_grad_scratch_bytes(self.n_pad, self.q))
-            self.partials = torch.empty(nbytes // 8, dtype=torch.float64, device=self.device)
+        if with_inverse:
+            # W = U^-T lives in the same buffer, right of the augmented block (include/plmc.h)
+            self.W = self.A[:, :, self.wcol0:self.wcol0 + self.n_pad]
+            self.ldw, self.strideW = self.lda, self.strideA
+            self.alpha = torch.empty(q, self.n_pad, dtype=dtype, device=device)
+            nbytes = int(L.cdll.plmc_grad_scratch_bytes(self.n_pad, q))
+            self.partials = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
 
 
 _ws_cache = {}
 
 
 def get_workspace(n, q, naug, dtype, device, need_grad):
-    key = (n, q, naug, dtype, device.index)
+    key = (n, q, naug, dtype, device.index, bool(need_grad))
     ws = _ws_cache.get(key)
     if ws is None:
-        if len(_ws_cache) > 4:
+        if len(_ws_cache) > 3:
             _ws_cache.clear()
         ws = Workspace(n, q, naug, dtype, device, need_grad)
         _ws_cache[key] = ws
-    elif need_grad:
-        ws.ensure_grad_buffers()
     return ws
 
 
@@ -92,12 +89,12 @@ def factorize(kind, X, ell, oscale, noise, rhs, ws, Xs=None):
            _hip.ptr(ws.A), ws.lda, ws.strideA, q, st)
     nrhs = 0 if rhs is None else rhs.shape[1]
     if ws.naug_pad > 0:
-        L.call("plmc_write_rhs", dt, _hip.ptr(rhs), nrhs, n, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, 1, q, st)
+        L.call("plmc_write_rhs", dt, _hip.ptr(rhs), nrhs, n, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, ws.naug_pad, q, st)
     if Xs is not None:
         L.call("plmc_assemble_cross", dt, k, _hip.ptr(X), n, _hip.ptr(Xs), Xs.shape[0], d, _hip.ptr(ell),
                _hip.ptr(oscale), _hip.ptr(ws.A), ws.lda, ws.strideA, ws.n_pad + nrhs, ws.n_pad, q, st)
     L.call("plmc_potrf", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.naug, ws.strideA, _hip.ptr(ws.Vd),
-           _hip.ptr(ws.logdet), _hip.ptr(ws.info), q, st)
+           _hip.ptr(ws.logdet), _hip.ptr(ws.info), int(ws.with_inverse), q, st)
 
 
 def factorize_checked(kind, X, ell, oscale, noise, rhs, ws, Xs=None):
@@ -151,8 +148,6 @@ class ExactLatentLogProb(torch.autograd.Function):
                _hip.ptr(ws.quad), q, st)
         logp = -0.5 * (ws.quad + ws.logdet + n * LOG2PI)
         if need_grad:
-            L.call("plmc_trtri", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, _hip.ptr(ws.Vd), _hip.ptr(ws.W),
-                   ws.ldw, ws.strideW, q, st)
             L.call("plmc_wt_matvec", dt, _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.z),
                    _hip.ptr(ws.alpha), q, st)
             grad = torch.empty(q, d + 2, dtype=torch.float64, device=dev)

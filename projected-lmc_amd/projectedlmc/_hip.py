@@ -24,9 +24,8 @@ _TYPED = {
     "plmc_assemble": [_I, _P, _I, _I, _P, _P, _P, _P, _L, _L, _I, _P],
     "plmc_write_rhs": [_P, _I, _I, _P, _L, _L, _I, _I, _I, _P],
     "plmc_assemble_cross": [_I, _P, _I, _P, _I, _I, _P, _P, _P, _L, _L, _L, _L, _I, _P],
-    "plmc_potrf": [_P, _L, _L, _I, _L, _P, _P, _P, _I, _P],
+    "plmc_potrf": [_P, _L, _L, _I, _L, _P, _P, _P, _I, _I, _P],
     "plmc_extract_col": [_P, _L, _L, _L, _I, _P, _P, _I, _P],
-    "plmc_trtri": [_P, _L, _L, _L, _P, _P, _L, _L, _I, _P],
     "plmc_wt_matvec": [_P, _L, _L, _L, _P, _P, _I, _P],
     "plmc_kinv_grad": [_I, _P, _L, _L, _L, _P, _P, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P],
 }
