@@ -59,12 +59,25 @@ def make_data(n, d, p, q, seed=0, dtype=torch.float32):
     return X.to(dtype), Y.to(dtype)
 
 
+def host_cores():
+    """Cores this process may actually use: min(affinity, cgroup CPU quota).  (On the GPU box
+    os.cpu_count() reports the whole host while the container is limited by cpu.max.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(X, Y, model_cpu_state, n_latents, budget_latents=1):
     """The oracle ("port": plain torch-CPU restatement, all host threads) timed on a bounded sample
     of the same step: `budget_latents` of the q latent MLL+gradient evaluations at full n.
     iters/sec = 1 / (q * t_per_latent)."""
     from oracle import cpu_step
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
     ell, noise, ytil = model_cpu_state
     n = X.shape[0]
     ts = []
@@ -154,6 +167,11 @@ def main():
         lp_init = _engine.exact_latent_log_prob("matern52", Xd, cpu_state[0].to(dev), None, cpu_state[1].to(dev),
                                                 cpu_state[2].to(dev))
         lp0_gpu = float(lp_init[0]) if rank == 0 else 0.0
+    def note(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    note("warm-up (%d steps)" % args.warmup)
     first_loss = None
     for i in range(args.warmup):
         l0 = step()
@@ -205,15 +223,20 @@ def main():
                                   "gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
                               for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])}
             res["kernel_ms_per_step"] = tot_ms / args.steps
-            # whole-step fractions the north_star asks for: F_chol = q n^3/3 over the potrf kernels,
-            # F_step = q n^3 over all dense kernels (local latents only)
+            # whole-step fractions the north_star asks for (local latents only).  The blocked sweep
+            # (k_diag + k_panel + k_trail) produces BOTH the Cholesky factor U and the inverse factor
+            # W = U^-T: F_sweep = 2 q n^3/3 ("Cholesky-GEMM roofline"); F_step = q n^3 over the whole step.
             q_loc = len(range(rank, q, world))
             chol_ms = sum(stats[k]["ms"] for k in ("k_diag", "k_panel", "k_trail") if k in stats) / args.steps
-            res["cholesky_gemm"] = {"tflops": q_loc * n ** 3 / 3 / (chol_ms * 1e-3) / 1e12, "ms_per_step": chol_ms,
-                                    "frac_of_mfma_peak": q_loc * n ** 3 / 3 / (chol_ms * 1e-3) / 1e12 / peak}
+            f_sweep = 2.0 * q_loc * n ** 3 / 3
+            res["cholesky_gemm"] = {"what": "factor U and inverse factor W in one sweep, 2 q n^3 / 3 flop",
+                                    "tflops": f_sweep / (chol_ms * 1e-3) / 1e12, "ms_per_step": chol_ms,
+                                    "frac_of_mfma_peak": f_sweep / (chol_ms * 1e-3) / 1e12 / peak}
             res["step_dense"] = {"tflops": q_loc * n ** 3 / (elapsed / args.steps) / 1e12,
                                  "frac_of_mfma_peak": q_loc * n ** 3 / (elapsed / args.steps) / 1e12 / peak}
+        note("%.2f ms/step on %d GPU(s)" % (1e3 * elapsed / args.steps, world))
         if world == 1 and not args.no_cpu_baseline:
+            note("timing the CPU oracle on %d host cores (bounded sample: 1 of %d latents) ..." % (host_cores(), q))
             cb, lp_cpu = cpu_baseline(X, Y, cpu_state, q)
             res["cpu_baseline"] = cb
             res["speedup_vs_cpu"] = its / cb["value"]
