@@ -134,6 +134,45 @@ int plmc_kinv_grad_f64(int kind, const double *W, int64_t n_pad, int64_t ldw, in
                        double *kinv_diag, void *partials, int q, void *stream);
 
 /*
+ * Exact (dense) LMC / ICM: Kronecker-structured coregionalisation.
+ * Replaces `MultitaskGPModel.forward` -> gpytorch LCMKernel / MultitaskKernel (:462-466, :586-589)
+ * + MultitaskGaussianLikelihood (experiments.py:184) and their autograd backward:
+ *     K_full = sum_i oscale_i k(X, X; ell_i) (x) B_i  +  I_n (x) Sigma      N = n*p rows, data-major
+ *     interleaved (flat index = i_point * p + i_task), B: q x p x p, Sigma: p x p (both symmetric).
+ * plmc_lmc_assemble_*  writes the upper tiles (identity padding up to plmc_pad(N)) of ONE factor buffer
+ *                      (batch 1); it is then factorised by plmc_potrf_* like any other matrix.
+ * plmc_lmc_cross_*     writes K_full(X, X*) (without Sigma) into columns [col0, col0 + ns*p).
+ * plmc_lmc_kinv_grad_* fused K_full^-1 = W^T W + gradient reduction; grad (fp64) has
+ *                      plmc_lmc_grad_len(p,q,d) entries laid out as
+ *                        [ dB: q*p*p | d ell: q*d | d oscale: q | d Sigma: p*p ]
+ *                      where dB / dSigma are accumulated over the UPPER triangle of K_full only
+ *                      (weight 2 off the diagonal): the caller symmetrises them, (G + G^T) / 2.
+ *                      partials: scratch of plmc_lmc_grad_scratch_bytes(N_pad, p, q, d) bytes.
+ */
+int64_t plmc_lmc_grad_len(int p, int q, int d);
+int64_t plmc_lmc_grad_scratch_bytes(int64_t N_pad, int p, int q, int d);
+int plmc_lmc_assemble_f32(int kind, const float *X, int n, int d, int p, int q, const float *ell,
+                          const float *oscale, const float *B, const float *Sigma, float *A,
+                          int64_t lda, void *stream);
+int plmc_lmc_assemble_f64(int kind, const double *X, int n, int d, int p, int q, const double *ell,
+                          const double *oscale, const double *B, const double *Sigma, double *A,
+                          int64_t lda, void *stream);
+int plmc_lmc_cross_f32(int kind, const float *X, int n, const float *Xs, int ns, int d, int p, int q,
+                       const float *ell, const float *oscale, const float *B, float *Out, int64_t ldo,
+                       int64_t col0, int64_t n_rows, void *stream);
+int plmc_lmc_cross_f64(int kind, const double *X, int n, const double *Xs, int ns, int d, int p, int q,
+                       const double *ell, const double *oscale, const double *B, double *Out,
+                       int64_t ldo, int64_t col0, int64_t n_rows, void *stream);
+int plmc_lmc_kinv_grad_f32(int kind, const float *W, int64_t N_pad, int64_t ldw, const float *alpha,
+                           const float *X, int n, int d, int p, int q, const float *ell,
+                           const float *oscale, const float *B, double *grad, void *partials,
+                           void *stream);
+int plmc_lmc_kinv_grad_f64(int kind, const double *W, int64_t N_pad, int64_t ldw, const double *alpha,
+                           const double *X, int n, int d, int p, int q, const double *ell,
+                           const double *oscale, const double *B, double *grad, void *partials,
+                           void *stream);
+
+/*
  * Optional per-kernel profiler (measurement only; the reference's counterpart is the wall-clock
  * `time.time()` around its loops, experiments.py:261,284).  While enabled, every kernel launch is
  * bracketed by two hipEvents on its launch stream.  plmc_prof_collect() waits for the recorded

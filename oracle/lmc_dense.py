@@ -48,11 +48,13 @@ def lmc_covariance(kind, X, ell, B, Sigma, nu=2.5, outputscale=None):
 
 
 def lmc_exact_mll(kind, X, Y, ell, B, Sigma, mean_const=None, nu=2.5, outputscale=None):
-    """ExactMarginalLogLikelihood of the exact LMC/ICM: log N(vec(Y - m); 0, C) / n."""
+    """ExactMarginalLogLikelihood of the exact LMC/ICM: log N(vec(Y - m); 0, C) / (n p)
+    [gpytorch-knowledge, v1.11: num_data = function_dist.event_shape.numel() = n * p for a
+    MultitaskMultivariateNormal -- the same expression the reference copies at projected_lmc.py:1194]."""
     n, p = Y.shape
     C = lmc_covariance(kind, X, ell, B, Sigma, nu, outputscale)
     R = Y if mean_const is None else Y - mean_const.reshape(1, p)
-    return gm.mvn_log_prob(C, R.reshape(-1)) / n
+    return gm.mvn_log_prob(C, R.reshape(-1)) / (n * p)
 
 
 def lmc_posterior(kind, X, Y, Xs, ell, B, Sigma, mean_const=None, nu=2.5, outputscale=None):

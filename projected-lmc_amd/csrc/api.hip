@@ -28,6 +28,29 @@ static hipEvent_t get_event() {
   return e;
 }
 
+// ---- helper stream + ordering events for the look-ahead of the blocked sweep (one per device,
+// created on first use; together with the profiler record this is all the process-global state).
+static hipStream_t g_side[64] = {nullptr};
+static hipEvent_t g_sync[64][4] = {{nullptr}};
+hipStream_t side_stream() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!g_side[dev]) {
+    // highest priority: the latency-bound chain must get CU slots ahead of the queued tail tiles
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&g_side[dev], hipStreamNonBlocking, hi) != hipSuccess) g_side[dev] = nullptr;
+  }
+  return g_side[dev];
+}
+hipEvent_t sync_event(int idx) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  hipEvent_t &e = g_sync[dev][idx & 3];
+  if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+  return e;
+}
+
 ProfScope::ProfScope(int id, hipStream_t st, double flops, double bytes) : idx_(-1), st_(st) {
   if (!g_prof_on || g_recs.size() >= (1u << 20)) return;
   ProfRec r{id, get_event(), get_event(), flops, bytes};

@@ -43,6 +43,9 @@ struct ProfScope {
   hipStream_t st_;
 };
 
+hipStream_t side_stream();          // per-device helper stream (api.hip), nullptr on failure
+hipEvent_t sync_event(int idx);     // per-device ordering events, idx in [0,4)
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace plmc

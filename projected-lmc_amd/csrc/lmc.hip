@@ -1,0 +1,320 @@
+// lmc.hip -- the exact (dense) LMC / ICM path: Kronecker-structured coregionalisation
+//     K_full = sum_i os_i K_i(X,X) (x) B_i + I_n (x) Sigma          ((n p) x (n p), data-major interleaved:
+//                                                                     flat index = i_point * p + i_task)
+// Replaces `MultitaskGPModel.forward` with gpytorch's LCMKernel / MultitaskKernel
+// (projected_lmc.py:462-466, 586-589) + MultitaskGaussianLikelihood (experiments.py:184) and the
+// autograd backward through them.  The (np x np) matrix goes through the same
+// blocked sweep (potrf.hip); this file adds
+//   k_lmc_assemble  : X, {ell_i, B_i}, Sigma -> upper tiles of K_full        (HBM-write bound)
+//   k_lmc_cross     : K_full(X, X*) into augmented columns (prediction)
+//   k_lmc_kinv_grad : K_full^-1 = W^T W tile on MFMA with the gradient w.r.t. every ell_ik, os_i,
+//                     B_i[s][t] and Sigma[s][t] reduced in the epilogue (LDS accumulators, fp64),
+//                     per-tile partials summed in fixed order by k_lmc_reduce.
+#include "api_common.hpp"
+#include "covariance.hpp"
+#include "../../include/plmc.h"
+
+namespace plmc {
+
+// Per-tile staging in LDS for the element-wise LMC evaluation: data point and task of each of the
+// 128 rows / columns of the tile, plus the small parameter tables.
+template <typename T> struct LmcTables {
+  T *xi, *xj;          // [128][d+1] raw inputs of the row / column data points (0 beyond N)
+  T *invl;             // [q][d]  1 / ell
+  T *os;               // [q]
+  T *B;                // [q][p][p]
+  T *Sg;               // [p][p]
+};
+
+template <typename T>
+__device__ __forceinline__ T *lmc_stage(T *base, LmcTables<T> &t, const T *X, int n, int d, int p, int q,
+                                         const T *ell, const T *oscale, const T *B, const T *Sigma, int row0, int col0) {
+  const int ldu = d + 1;
+  t.xi = base; t.xj = t.xi + NB * ldu; t.invl = t.xj + NB * ldu; t.os = t.invl + q * d;
+  t.B = t.os + q; t.Sg = t.B + q * p * p;
+  T *end = t.Sg + p * p;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NB * d; e += NTHREADS) {
+    int r = e / d, k = e % d;
+    int a = (row0 + r) / p, b = (col0 + r) / p;
+    t.xi[r * ldu + k] = a < n ? X[(int64_t)a * d + k] : T(0);
+    t.xj[r * ldu + k] = b < n ? X[(int64_t)b * d + k] : T(0);
+  }
+  for (int e = tid; e < q * d; e += NTHREADS) t.invl[e] = T(1) / ell[e];
+  for (int e = tid; e < q; e += NTHREADS) t.os[e] = oscale ? oscale[e] : T(1);
+  for (int e = tid; e < q * p * p; e += NTHREADS) t.B[e] = B[e];
+  if (Sigma) for (int e = tid; e < p * p; e += NTHREADS) t.Sg[e] = Sigma[e];
+  return end;
+}
+
+// grid (m, m): upper tiles of the N_pad x N_pad matrix (N = n p).
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_lmc_assemble(int kind, const T *__restrict__ X, int n, int d, int p, int q,
+                                                            const T *__restrict__ ell, const T *__restrict__ oscale,
+                                                            const T *__restrict__ B, const T *__restrict__ Sigma,
+                                                            T *__restrict__ A, int64_t lda) {
+  const int jb = blockIdx.x, ib = blockIdx.y;
+  if (jb < ib) return;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  LmcTables<T> t;
+  lmc_stage<T>(reinterpret_cast<T *>(smem_raw), t, X, n, d, p, q, ell, oscale, B, Sigma, ib * NB, jb * NB);
+  __syncthreads();
+  const int64_t N = (int64_t)n * p;
+  const int ldu = d + 1, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  for (int rr = 0; rr < 8; ++rr) {
+    const int r = ty + 16 * rr;
+    const int64_t I = (int64_t)ib * NB + r;
+    const int a = (int)(I / p), s = (int)(I % p);
+    for (int h = 0; h < 2; ++h) {
+      const int c0 = tx * 4 + 64 * h;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int64_t J = (int64_t)jb * NB + c0 + c;
+        T val;
+        if (I < N && J < N) {
+          const int b = (int)(J / p), tt = (int)(J % p);
+          val = (a == b) ? t.Sg[s * p + tt] : T(0);
+          for (int i = 0; i < q; ++i) {
+            T r2 = T(0);
+            for (int k = 0; k < d; ++k) {
+              T df = (t.xi[r * ldu + k] - t.xj[(c0 + c) * ldu + k]) * t.invl[i * d + k];
+              r2 += df * df;
+            }
+            val += t.os[i] * kern_value<T>(kind, r2) * t.B[(i * p + s) * p + tt];
+          }
+        } else {
+          val = (I == J) ? T(1) : T(0);
+        }
+        A[I * lda + J] = val;
+      }
+    }
+  }
+}
+
+// Out[(a,s)][col0 + b*p + t] = sum_i os_i k_i(x_a, xs_b) B_i[s][t]; rows >= N zero.  block 64 x 4.
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_lmc_cross(int kind, const T *__restrict__ X, int n, const T *__restrict__ Xs,
+                                                         int ns, int d, int p, int q, const T *__restrict__ ell,
+                                                         const T *__restrict__ oscale, const T *__restrict__ B,
+                                                         T *__restrict__ Out, int64_t ldo, int64_t col0, int64_t n_rows) {
+  const int64_t J = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int64_t I = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (J >= (int64_t)ns * p || I >= n_rows) return;
+  T val = T(0);
+  if (I < (int64_t)n * p) {
+    const int a = (int)(I / p), s = (int)(I % p), b = (int)(J / p), tt = (int)(J % p);
+    for (int i = 0; i < q; ++i) {
+      T r2 = T(0);
+      for (int k = 0; k < d; ++k) {
+        T df = (X[(int64_t)a * d + k] - Xs[(int64_t)b * d + k]) / ell[i * d + k];
+        r2 += df * df;
+      }
+      val += (oscale ? oscale[i] : T(1)) * kern_value<T>(kind, r2) * B[(i * p + s) * p + tt];
+    }
+  }
+  Out[I * ldo + col0 + J] = val;
+}
+
+// Number of fp64 accumulators per tile: [q*p*p dB | q*d d ell | q d os | p*p dSigma].
+__host__ __device__ inline int lmc_nacc(int p, int q, int d) { return q * p * p + q * d + q + p * p; }
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_lmc_kinv_grad(int kind, const T *__restrict__ W, int64_t N_pad, int64_t ldw,
+                                                             const T *__restrict__ alpha, const T *__restrict__ X,
+                                                             int n, int d, int p, int q, const T *__restrict__ ell,
+                                                             const T *__restrict__ oscale, const T *__restrict__ B,
+                                                             double *__restrict__ partials) {
+  const int jb = blockIdx.x, ib = blockIdx.y;
+  if (jb < ib) return;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T *smem = reinterpret_cast<T *>(smem_raw);
+  const int m = (int)(N_pad / NB);
+  const T *Wl = W + (int64_t)jb * NB * ldw;
+  Acc<T> acc;
+  acc.zero();
+  tile_mainloop<T, false, true>(acc, Wl + (int64_t)ib * NB, ldw, Wl + (int64_t)jb * NB, ldw,
+                                (int)(N_pad - (int64_t)jb * NB), smem);
+  // ---- epilogue
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  LmcTables<T> t;
+  T *end = lmc_stage<T>(smem, t, X, n, d, p, q, ell, oscale, B, (const T *)nullptr, ib * NB, jb * NB);
+  T *ai = end, *aj = ai + NB;
+  const int nacc = lmc_nacc(p, q, d);
+  uintptr_t ap = (reinterpret_cast<uintptr_t>(aj + NB) + 7) & ~(uintptr_t)7;
+  double *accs = reinterpret_cast<double *>(ap);
+  double *gB = accs, *gL = gB + q * p * p, *gO = gL + q * d, *gS = gO + q;
+  if (tid < NB) {
+    ai[tid] = alpha[ib * NB + tid];
+    aj[tid] = alpha[jb * NB + tid];
+  }
+  for (int e = tid; e < nacc; e += NTHREADS) accs[e] = 0.0;
+  __syncthreads();
+  const int64_t N = (int64_t)n * p;
+  const int ldu = d + 1;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+      const int row = tile_row<T>(wm, mt, lane, r);
+      const int64_t I = (int64_t)ib * NB + row;
+      const int a = (int)(I / p), s = (int)(I % p);
+      const T a_i = ai[row];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int col = tile_col(wn, nt, lane);
+        const int64_t J = (int64_t)jb * NB + col;
+        const auto &av = acc.v[mt][nt];
+        const T kin = r == 0 ? av[0] : (r == 1 ? av[1] : (r == 2 ? av[2] : av[3]));
+        if (I < N && J < N && J >= I) {
+          const int b = (int)(J / p), tt = (int)(J % p);
+          const T wij = (I == J ? T(1) : T(2)) * (a_i * aj[col] - kin);
+          if (a == b) atomicAdd(&gS[s * p + tt], (double)wij);
+          for (int i = 0; i < q; ++i) {
+            T r2 = T(0);
+            for (int k = 0; k < d; ++k) {
+              T df = (t.xi[row * ldu + k] - t.xj[col * ldu + k]) * t.invl[i * d + k];
+              r2 += df * df;
+            }
+            T val, base;
+            kern_value_base<T>(kind, r2, val, base);
+            const T bst = t.B[(i * p + s) * p + tt];
+            atomicAdd(&gB[(i * p + s) * p + tt], (double)(wij * t.os[i] * val));
+            atomicAdd(&gO[i], (double)(wij * val * bst));
+            if (a != b) {
+              const T c = wij * t.os[i] * bst * base;
+              for (int k = 0; k < d; ++k) {
+                T df = (t.xi[row * ldu + k] - t.xj[col * ldu + k]) * t.invl[i * d + k];
+                atomicAdd(&gL[i * d + k], (double)(c * df * df));
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  double *out = partials + ((int64_t)ib * m + jb) * nacc;
+  for (int e = tid; e < nacc; e += NTHREADS) out[e] = accs[e];
+}
+
+// grad[e] = 1/2 sum over upper tiles (fixed order); lengthscale entries additionally / ell.  grid (ceil(nacc/256)).
+template <typename T>
+__global__ void k_lmc_reduce(const double *__restrict__ partials, int m, int nacc, int p, int q, int d,
+                             const T *__restrict__ ell, double *__restrict__ grad) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nacc) return;
+  double s = 0.0;
+  for (int ib = 0; ib < m; ++ib)
+    for (int jb = ib; jb < m; ++jb) s += partials[((int64_t)ib * m + jb) * nacc + e];
+  s *= 0.5;
+  const int l0 = q * p * p;
+  if (e >= l0 && e < l0 + q * d) s /= (double)ell[e - l0];
+  grad[e] = s;
+}
+
+template <typename T> size_t lmc_stage_elems(int p, int q, int d) {
+  return (size_t)2 * NB * (d + 1) + (size_t)q * d + q + (size_t)q * p * p + (size_t)p * p;
+}
+
+template <typename T>
+int lmc_assemble_impl(int kind, const T *X, int n, int d, int p, int q, const T *ell, const T *oscale, const T *B,
+                      const T *Sigma, T *A, int64_t lda, void *stream) {
+  PLMC_REQUIRE(kind >= 0 && kind <= 3, "unknown kernel kind");
+  PLMC_REQUIRE(X && ell && B && Sigma && A, "null pointer");
+  PLMC_REQUIRE(n > 0 && p > 0 && q > 0 && d > 0 && d <= MAX_DIM, "bad sizes");
+  const int64_t N_pad = plmc_pad((int64_t)n * p);
+  PLMC_REQUIRE(lda >= N_pad && lda % NB == 0, "lda must be a multiple of NB and >= plmc_pad(n*p)");
+  const size_t smem = lmc_stage_elems<T>(p, q, d) * sizeof(T);
+  PLMC_REQUIRE(smem <= 150 * 1024, "q*p*p too large for the LDS parameter tables");
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lmc_assemble<T>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  const int m = (int)(N_pad / NB);
+  ProfScope ps(PK_ASSEMBLE, (hipStream_t)stream, 0.0, ((double)N_pad * N_pad / 2) * sizeof(T));
+  hipLaunchKernelGGL(k_lmc_assemble<T>, dim3(m, m), dim3(NTHREADS), smem, (hipStream_t)stream, kind, X, n, d, p, q, ell,
+                     oscale, B, Sigma, A, lda);
+  return launch_status(__func__);
+}
+
+template <typename T>
+int lmc_cross_impl(int kind, const T *X, int n, const T *Xs, int ns, int d, int p, int q, const T *ell, const T *oscale,
+                   const T *B, T *Out, int64_t ldo, int64_t col0, int64_t n_rows, void *stream) {
+  PLMC_REQUIRE(kind >= 0 && kind <= 3, "unknown kernel kind");
+  PLMC_REQUIRE(X && Xs && ell && B && Out, "null pointer");
+  PLMC_REQUIRE(n > 0 && ns > 0 && p > 0 && q > 0 && d > 0 && d <= MAX_DIM, "bad sizes");
+  PLMC_REQUIRE(n_rows >= (int64_t)n * p && col0 >= 0 && col0 + (int64_t)ns * p <= ldo, "cross block exceeds the buffer");
+  const int64_t nc = (int64_t)ns * p;
+  ProfScope ps(PK_CROSS, (hipStream_t)stream, 0.0, (double)n_rows * nc * sizeof(T));
+  hipLaunchKernelGGL(k_lmc_cross<T>, dim3((unsigned)((nc + 63) / 64), (unsigned)((n_rows + 3) / 4)), dim3(NTHREADS), 0,
+                     (hipStream_t)stream, kind, X, n, Xs, ns, d, p, q, ell, oscale, B, Out, ldo, col0, n_rows);
+  return launch_status(__func__);
+}
+
+template <typename T>
+int lmc_kinv_grad_impl(int kind, const T *W, int64_t N_pad, int64_t ldw, const T *alpha, const T *X, int n, int d, int p,
+                       int q, const T *ell, const T *oscale, const T *B, double *grad, void *partials, void *stream) {
+  PLMC_REQUIRE(kind >= 0 && kind <= 3, "unknown kernel kind");
+  PLMC_REQUIRE(W && alpha && X && ell && B && grad && partials, "null pointer");
+  PLMC_REQUIRE(n > 0 && p > 0 && q > 0 && d > 0 && d <= MAX_DIM, "bad sizes");
+  PLMC_REQUIRE(N_pad == plmc_pad((int64_t)n * p) && ldw % NB == 0 && aligned16(W), "N_pad must be plmc_pad(n*p)");
+  const int nacc = lmc_nacc(p, q, d);
+  size_t epi = (lmc_stage_elems<T>(p, q, d) + 2 * NB) * sizeof(T) + 8 + (size_t)nacc * sizeof(double);
+  size_t smem = (size_t)tile_smem_elems<T>() * sizeof(T);
+  if (epi > smem) smem = epi;
+  PLMC_REQUIRE(smem <= 150 * 1024, "q*p*p too large for the LDS accumulators");
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lmc_kinv_grad<T>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipStream_t st = (hipStream_t)stream;
+  const int m = (int)(N_pad / NB);
+  double *part = reinterpret_cast<double *>(partials);
+  {
+    const double np = (double)N_pad;
+    ProfScope ps(PK_KINV_GRAD, st, np * np * np / 3.0, (np * np / 2) * sizeof(T));
+    hipLaunchKernelGGL(k_lmc_kinv_grad<T>, dim3(m, m), dim3(NTHREADS), smem, st, kind, W, N_pad, ldw, alpha, X, n, d, p,
+                       q, ell, oscale, B, part);
+  }
+  {
+    ProfScope ps(PK_REDUCE, st, 0.0, (double)m * m / 2 * nacc * 8);
+    hipLaunchKernelGGL(k_lmc_reduce<T>, dim3((nacc + 255) / 256), dim3(256), 0, st, part, m, nacc, p, q, d, ell, grad);
+  }
+  return launch_status(__func__);
+}
+
+}  // namespace plmc
+
+extern "C" {
+int64_t plmc_lmc_grad_len(int p, int q, int d) { return plmc::lmc_nacc(p, q, d); }
+int64_t plmc_lmc_grad_scratch_bytes(int64_t N_pad, int p, int q, int d) {
+  int64_t m = N_pad / plmc::NB;
+  return m * m * (int64_t)plmc::lmc_nacc(p, q, d) * (int64_t)sizeof(double);
+}
+int plmc_lmc_assemble_f32(int kind, const float *X, int n, int d, int p, int q, const float *ell, const float *oscale,
+                          const float *B, const float *Sigma, float *A, int64_t lda, void *stream) {
+  return plmc::lmc_assemble_impl<float>(kind, X, n, d, p, q, ell, oscale, B, Sigma, A, lda, stream);
+}
+int plmc_lmc_assemble_f64(int kind, const double *X, int n, int d, int p, int q, const double *ell, const double *oscale,
+                          const double *B, const double *Sigma, double *A, int64_t lda, void *stream) {
+  return plmc::lmc_assemble_impl<double>(kind, X, n, d, p, q, ell, oscale, B, Sigma, A, lda, stream);
+}
+int plmc_lmc_cross_f32(int kind, const float *X, int n, const float *Xs, int ns, int d, int p, int q, const float *ell,
+                       const float *oscale, const float *B, float *Out, int64_t ldo, int64_t col0, int64_t n_rows,
+                       void *stream) {
+  return plmc::lmc_cross_impl<float>(kind, X, n, Xs, ns, d, p, q, ell, oscale, B, Out, ldo, col0, n_rows, stream);
+}
+int plmc_lmc_cross_f64(int kind, const double *X, int n, const double *Xs, int ns, int d, int p, int q, const double *ell,
+                       const double *oscale, const double *B, double *Out, int64_t ldo, int64_t col0, int64_t n_rows,
+                       void *stream) {
+  return plmc::lmc_cross_impl<double>(kind, X, n, Xs, ns, d, p, q, ell, oscale, B, Out, ldo, col0, n_rows, stream);
+}
+int plmc_lmc_kinv_grad_f32(int kind, const float *W, int64_t N_pad, int64_t ldw, const float *alpha, const float *X, int n,
+                           int d, int p, int q, const float *ell, const float *oscale, const float *B, double *grad,
+                           void *partials, void *stream) {
+  return plmc::lmc_kinv_grad_impl<float>(kind, W, N_pad, ldw, alpha, X, n, d, p, q, ell, oscale, B, grad, partials,
+                                         stream);
+}
+int plmc_lmc_kinv_grad_f64(int kind, const double *W, int64_t N_pad, int64_t ldw, const double *alpha, const double *X,
+                           int n, int d, int p, int q, const double *ell, const double *oscale, const double *B,
+                           double *grad, void *partials, void *stream) {
+  return plmc::lmc_kinv_grad_impl<double>(kind, W, N_pad, ldw, alpha, X, n, d, p, q, ell, oscale, B, grad, partials,
+                                          stream);
+}
+}

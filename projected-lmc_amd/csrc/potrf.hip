@@ -137,7 +137,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   PLMC_REQUIRE(naug >= 0 && n_pad + naug_pad + (with_inverse ? n_pad : 0) <= lda,
                "lda too small for naug (+ the n_pad columns of the inverse factor)");
   PLMC_REQUIRE(q > 0 && aligned16(A) && aligned16(Vd), "bad q or unaligned buffer");
-  hipStream_t st = (hipStream_t)stream;
+  const hipStream_t st = (hipStream_t)stream;
   const int m = (int)(n_pad / NB);
   const int Taug = (int)(naug_pad / NB);
   const int64_t strideV = (int64_t)m * NB * NB;
@@ -151,13 +151,13 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   }
   const double nb = (double)NB, nb3 = nb * nb * nb, esz = sizeof(T);
 
-  auto diag = [&](int r) {
+  auto diag = [&](int r, hipStream_t st) {
     ProfScope ps(PK_DIAG, st, q * (2.0 / 3.0) * nb3, q * 3.0 * nb * nb * esz);
     T *wout = with_inverse ? A + (int64_t)r * NB * lda + wcol0 + (int64_t)r * NB : (T *)nullptr;
     hipLaunchKernelGGL(k_diag<T>, dim3(q), dim3(NTHREADS), diag_smem, st, A, lda, strideA, r, Vd, strideV, wout, lda,
                        strideA, logdet, info);
   };
-  auto panel = [&](int r) {
+  auto panel = [&](int r, hipStream_t st) {
     ColMap cm{r + 1, m - 1 - r, Taug, with_inverse ? r : 0, n_pad, wcol0};
     const int nt = cm.nU + cm.Taug + cm.nW;
     if (nt == 0) return;
@@ -165,7 +165,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     ProfScope ps(PK_PANEL, st, q * (double)nt * nb3, q * 2.0 * nt * nb * nb * esz);
     hipLaunchKernelGGL(k_panel<T>, dim3(nt, q), dim3(NTHREADS), 0, st, A, lda, strideA, r, cm, Vd, strideV);
   };
-  auto update = [&](int ib0, int nrows, int r_lo, int r_hi) {
+  auto update = [&](int ib0, int nrows, int r_lo, int r_hi, hipStream_t st) {
     if (nrows <= 0) return;
     ColMap cm{ib0, m - ib0, Taug, with_inverse ? r_hi + 1 : 0, n_pad, wcol0};
     const double depth = (r_hi - r_lo + 1) * nb;
@@ -181,16 +181,43 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
                        ib0, r_lo, r_hi, cm);
   };
 
-  for (int r0 = 0; r0 < m; r0 += 2) {
-    const int r1 = r0 + 1;
-    diag(r0);
-    panel(r0);
-    if (r1 < m) {
-      update(r1, 1, r0, r0);
-      diag(r1);
-      panel(r1);
-      update(r1 + 1, m - r1 - 1, r0, r1);
+  // One pair of block rows: factor/invert the two diagonal blocks and solve their row panels.
+  auto chain = [&](int r0, hipStream_t s) {
+    diag(r0, s);
+    panel(r0, s);
+    if (r0 + 1 < m) {
+      update(r0 + 1, 1, r0, r0, s);
+      diag(r0 + 1, s);
+      panel(r0 + 1, s);
     }
+  };
+  // Look-ahead: the depth-256 update of pair K is split into the two block rows the next pair needs
+  // ("head") and the rest ("tail"); the latency-bound chain of pair K+1 runs on a helper stream
+  // concurrently with the tail.  Falls back to a single stream if the helper cannot be created.
+  hipStream_t s1 = side_stream();
+  hipEvent_t e_head = sync_event(0), e_chain = sync_event(1), e_entry = sync_event(2);
+  const bool la = s1 && e_head && e_chain && e_entry && m > 4;
+  if (la) {
+    (void)hipEventRecord(e_entry, st);
+    (void)hipStreamWaitEvent(s1, e_entry, 0);
+  }
+  chain(0, st);
+  for (int r0 = 0; r0 + 1 < m; r0 += 2) {
+    const int r1 = r0 + 1, first = r1 + 1, nrest = m - first;
+    if (nrest <= 0) break;
+    if (!la) {
+      update(first, nrest, r0, r1, st);
+      chain(first, st);
+      continue;
+    }
+    const int nhead = nrest < 2 ? nrest : 2;
+    update(first, nhead, r0, r1, st);
+    (void)hipEventRecord(e_head, st);
+    (void)hipStreamWaitEvent(s1, e_head, 0);
+    chain(first, s1);
+    (void)hipEventRecord(e_chain, s1);
+    update(first + nhead, nrest - nhead, r0, r1, st);
+    (void)hipStreamWaitEvent(st, e_chain, 0);
   }
   return launch_status(__func__);
 }

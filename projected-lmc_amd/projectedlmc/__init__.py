@@ -7,7 +7,7 @@ users touch (kernels, means, likelihoods, distributions, mlls, settings, constra
 provided here as thin modules with the same names and parameter layout.
 """
 from . import settings, constraints, kernels, means, likelihoods, distributions, mlls, parallel  # noqa: F401
-from .kernels import RBFKernel, MaternKernel, ScaleKernel  # noqa: F401
+from .kernels import RBFKernel, MaternKernel, ScaleKernel, MultitaskKernel, LCMKernel, IndexKernel  # noqa: F401
 from .means import ZeroMean, ConstantMean, MultitaskMean  # noqa: F401
 from .likelihoods import GaussianLikelihood, MultitaskGaussianLikelihood  # noqa: F401
 from .distributions import MultivariateNormal, MultitaskMultivariateNormal  # noqa: F401
@@ -15,3 +15,4 @@ from .mlls import ExactMarginalLogLikelihood  # noqa: F401
 from .models import (ExactGPModel, handle_covar_, init_lmc_coefficients, ScalarParam,  # noqa: F401
                      PositiveDiagonalParam, UpperTriangularParam, LowerTriangularParam)
 from .projected import LMCMixingMatrix, ProjectedGPModel, ProjectedLMCmll  # noqa: F401
+from .multitask import MultitaskGPModel  # noqa: F401

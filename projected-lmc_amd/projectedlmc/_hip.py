@@ -28,6 +28,9 @@ _TYPED = {
     "plmc_extract_col": [_P, _L, _L, _L, _I, _P, _P, _I, _P],
     "plmc_wt_matvec": [_P, _L, _L, _L, _P, _P, _I, _P],
     "plmc_kinv_grad": [_I, _P, _L, _L, _L, _P, _P, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P],
+    "plmc_lmc_assemble": [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P],
+    "plmc_lmc_cross": [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _P],
+    "plmc_lmc_kinv_grad": [_I, _P, _L, _L, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
 }
 _PLAIN = {
     "plmc_version": ([], _I),
@@ -36,6 +39,8 @@ _PLAIN = {
     "plmc_max_dim": ([], _I),
     "plmc_last_error": ([], _c.c_char_p),
     "plmc_grad_scratch_bytes": ([_L, _I], _L),
+    "plmc_lmc_grad_len": ([_I, _I, _I], _L),
+    "plmc_lmc_grad_scratch_bytes": ([_L, _I, _I, _I], _L),
     "plmc_prof_enable": ([_I], _I),
     "plmc_prof_kernels": ([], _I),
     "plmc_prof_name": ([_I], _c.c_char_p),

@@ -146,3 +146,115 @@ class LazyKernel:
 
     to_dense = evaluate
     evaluate_kernel = lambda self: self  # noqa: E731  (gpytorch idiom used at projected_lmc.py:368)
+
+
+# ------------------------------------------------------------------------------------------------
+# Multitask (Kronecker) kernels of the exact LMC / ICM models (projected_lmc.py:462-466).
+class IndexKernel(torch.nn.Module):
+    """Task covariance B = F F^T + diag(softplus(raw_var)) [gpytorch-knowledge: IndexKernel;
+    covar_factor (p x rank) and raw_var (p) are randn-initialised]."""
+
+    def __init__(self, num_tasks, rank=1, **kwargs):
+        super().__init__()
+        self.num_tasks, self.rank = num_tasks, rank
+        self.register_parameter("covar_factor", torch.nn.Parameter(torch.randn(num_tasks, rank)))
+        self.register_parameter("raw_var", torch.nn.Parameter(torch.randn(num_tasks)))
+        self.raw_var_constraint = Positive()
+
+    @property
+    def var(self):
+        return self.raw_var_constraint.transform(self.raw_var)
+
+    @property
+    def covar_matrix(self):
+        F = self.covar_factor
+        return F @ F.transpose(-1, -2) + torch.diag_embed(self.var.to(F.dtype))
+
+
+class MultitaskKernel(Kernel):
+    """K_data(x,x') (x) B (data-major interleaving) [gpytorch-knowledge: MultitaskKernel]."""
+
+    def __init__(self, data_covar_module, num_tasks, rank=1, **kwargs):
+        super().__init__()
+        self.data_covar_module = data_covar_module
+        self.task_covar_module = IndexKernel(num_tasks=num_tasks, rank=rank)
+        self.num_tasks = num_tasks
+
+    def _lmc_pieces(self, d):
+        kind, ell, osc = self.data_covar_module._pieces(d)
+        return kind, ell[:1], None if osc is None else osc[:1], self.task_covar_module.covar_matrix.unsqueeze(0)
+
+    def forward(self, x1, x2=None, **params):
+        x1 = self.data_covar_module.select(x1)
+        kind, ell, osc, B = self._lmc_pieces(x1.shape[-1])
+        return LazyLmcKernel(kind, x1, ell, osc, B)
+
+
+class LCMKernel(Kernel):
+    """sum_i K_i (x) B_i, one MultitaskKernel per latent [gpytorch-knowledge: LCMKernel]."""
+
+    def __init__(self, base_kernels, num_tasks, rank=1, **kwargs):
+        super().__init__()
+        self.covar_module_list = torch.nn.ModuleList(
+            [MultitaskKernel(b, num_tasks=num_tasks, rank=rank) for b in base_kernels])
+        self.num_tasks = num_tasks
+
+    def forward(self, x1, x2=None, **params):
+        x1 = self.covar_module_list[0].data_covar_module.select(x1)
+        pieces = [m._lmc_pieces(x1.shape[-1]) for m in self.covar_module_list]
+        kind = pieces[0][0]
+        ell = torch.cat([p_[1] for p_ in pieces], 0)
+        osc = None if pieces[0][2] is None else torch.cat([p_[2] for p_ in pieces], 0)
+        B = torch.cat([p_[3] for p_ in pieces], 0)
+        return LazyLmcKernel(kind, x1, ell, osc, B)
+
+
+class LazyLmcKernel:
+    """Un-evaluated sum_i os_i k(X,X; ell_i) (x) B_i (+ I (x) Sigma once a multitask likelihood was
+    applied); consumed by the HIP LMC engine."""
+
+    def __init__(self, kind, x, ell, oscale, B, task_noise=None):
+        self.kind, self.x, self.ell, self.oscale, self.B, self.task_noise = kind, x, ell, oscale, B, task_noise
+
+    @property
+    def shape(self):
+        N = self.x.shape[-2] * self.B.shape[-1]
+        return torch.Size([N, N])
+
+    def add_task_noise(self, Sigma):
+        tn = Sigma if self.task_noise is None else self.task_noise + Sigma
+        return LazyLmcKernel(self.kind, self.x, self.ell, self.oscale, self.B, tn)
+
+    def diagonal(self, *a, **k):
+        q = self.ell.shape[0]
+        os_ = torch.ones(q, dtype=self.B.dtype, device=self.B.device) if self.oscale is None else self.oscale
+        dg = (os_[:, None] * torch.diagonal(self.B, dim1=-2, dim2=-1)).sum(0)
+        if self.task_noise is not None:
+            dg = dg + torch.diagonal(self.task_noise)
+        return dg.repeat(self.x.shape[-2])
+
+    def log_prob_flat(self, diff):
+        from . import _lmc_engine
+        if self.task_noise is None:
+            raise RuntimeError("log_prob of a noise-free LMC prior: apply the multitask likelihood first")
+        return _lmc_engine.lmc_exact_log_prob(self.kind, self.x, self.ell, self.oscale, self.B, self.task_noise,
+                                              diff.reshape(-1))
+
+    def evaluate(self):
+        """Dense (np x np) matrix via the HIP cross kernel (small cases / inspection only)."""
+        from . import _hip
+        L = _hip.lib()
+        x = self.x.contiguous()
+        n, d = x.shape
+        q, p = self.B.shape[0], self.B.shape[-1]
+        dt, dev = self.B.dtype, self.B.device
+        out = torch.empty(n * p, n * p, dtype=dt, device=dev)
+        L.call("plmc_lmc_cross", dt, _hip.KIND[self.kind], _hip.ptr(x.to(dt)), n, _hip.ptr(x.to(dt)), n, d, p, q,
+               _hip.ptr(self.ell.detach().to(dt).contiguous()),
+               _hip.ptr(None if self.oscale is None else self.oscale.detach().to(dt).contiguous()),
+               _hip.ptr(self.B.detach().contiguous()), _hip.ptr(out), n * p, 0, n * p, _hip.stream_ptr(dev))
+        if self.task_noise is not None:
+            out = out + torch.kron(torch.eye(n, dtype=dt, device=dev), self.task_noise.detach())
+        return out
+
+    to_dense = evaluate

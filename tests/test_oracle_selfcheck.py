@@ -174,7 +174,7 @@ def test_lmc_exact_mll_rank1_equals_projected_dense():
     S = ld.task_noise_covariance(3, raw_task_noises=torch.zeros(3), raw_noise=torch.zeros(1))
     v = ld.lmc_exact_mll("rbf", X, Y, ell, B, S)
     C = ld.lmc_covariance("rbf", X, ell, B, S)
-    ref = torch.distributions.MultivariateNormal(torch.zeros(60), C).log_prob(Y.reshape(-1)) / 20
+    ref = torch.distributions.MultivariateNormal(torch.zeros(60), C).log_prob(Y.reshape(-1)) / 60
     assert torch.allclose(v, ref)
     # interleaving: entry ((a,s),(b,t)) = sum_i K_i[a,b] B_i[s,t] + delta_ab Sigma[s,t]
     K = gm.kernel_matrix("rbf", X, X, ell)
