@@ -173,6 +173,22 @@ int plmc_lmc_kinv_grad_f64(int kind, const double *W, int64_t N_pad, int64_t ldw
                            void *stream);
 
 /*
+ * Vector-Jacobian product of a dense (cross-)covariance block K_i[a][b] = oscale_i k(|x1_a - x2_b| / ell_i)
+ * given G = d loss / d K (q x n1 x n2, row stride ldg, batch stride strideG).  Row partials in fp64:
+ *   gX1 [q][n1][d] = sum_b G dK/dx1_a,   gEll[q][n1][d] = sum_b G dK/d ell  (caller sums over rows),
+ *   gOs [q][n1]    = sum_b G dK/d oscale.
+ * Variational path: gradients of K_ZZ / K_ZX w.r.t. the learned inducing
+ * locations and lengthscales of VariationalMultitaskGPModel (projected_lmc.py:686-766), which the
+ * reference obtains from torch autograd through gpytorch's kernel evaluation (experiments.py:270).
+ */
+int plmc_kernel_vjp_f32(int kind, const float *X1, int n1, const float *X2, int n2, int d,
+                        const float *ell, const float *oscale, const float *G, int64_t ldg,
+                        int64_t strideG, double *gX1, double *gEll, double *gOs, int q, void *stream);
+int plmc_kernel_vjp_f64(int kind, const double *X1, int n1, const double *X2, int n2, int d,
+                        const double *ell, const double *oscale, const double *G, int64_t ldg,
+                        int64_t strideG, double *gX1, double *gEll, double *gOs, int q, void *stream);
+
+/*
  * Optional per-kernel profiler (measurement only; the reference's counterpart is the wall-clock
  * `time.time()` around its loops, experiments.py:261,284).  While enabled, every kernel launch is
  * bracketed by two hipEvents on its launch stream.  plmc_prof_collect() waits for the recorded

@@ -119,6 +119,15 @@ class MultitaskGaussianLikelihood(_GaussianLikelihoodBase):
             S = S + self.noise.reshape(()) * torch.eye(self.num_tasks, dtype=ref.dtype, device=ref.device)
         return S if dtype is None else S.to(dtype)
 
+    def expected_log_prob(self, target, input, *params, **kwargs):
+        """E_q(f)[log p(y|f)] per data point; like gpytorch's _GaussianLikelihoodBase it uses only the
+        marginal variances of q(f) and the DIAGONAL of the task-noise covariance [gpytorch-knowledge]."""
+        import math
+        mean, variance = input.mean, input.variance
+        noise = torch.diagonal(self.task_noise_matrix(mean.dtype)).reshape(1, -1)
+        res = ((target - mean).square() + variance) / noise + noise.log() + math.log(2 * math.pi)
+        return res.mul(-0.5).sum(-1)
+
     def forward(self, function_dist, *params, **kwargs):
         c = function_dist.lazy_covariance_matrix
         Sigma = self.task_noise_matrix(function_dist.mean.dtype)

@@ -1,0 +1,104 @@
+"""GPU parity of the variational LMC path (`VariationalMultitaskGPModel` + `VariationalELBO`,
+SURVEY.md 8a row a12 / BASELINE config 4) against the CPU oracle: ELBO value and the gradient of
+every parameter, including the learned inducing locations."""
+import warnings
+
+import pytest
+import torch
+
+from oracle import variational as ov
+from oracle import gp_math as gm
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def plmc():
+    import projectedlmc
+    assert torch.cuda.is_available()
+    return projectedlmc
+
+
+def _build(plmc, n, d, p, q, kernel, oscale, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    X = (2 * torch.rand(n, d, generator=g, dtype=torch.float64) - 1).to(dtype)
+    Y = torch.randn(n, p, generator=g, dtype=torch.float64).to(dtype)
+    torch.manual_seed(seed)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        lik = plmc.MultitaskGaussianLikelihood(num_tasks=p, rank=2)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = plmc.VariationalMultitaskGPModel(X, n_latents=q, n_tasks=p, train_ind_ratio=1.5, seed=0,
+                                                     init_lmc_coeffs=True, train_y=Y, mean_type=plmc.ConstantMean,
+                                                     kernel_type=getattr(plmc, kernel), outputscales=oscale)
+    finally:
+        torch.set_default_dtype(old)
+    g2 = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for name, prm in list(model.named_parameters()) + list(lik.named_parameters()):
+            prm.add_(0.1 * torch.randn(prm.shape, generator=g2, dtype=torch.float64).to(prm.dtype))
+    model.variational_strategy.base_variational_strategy.variational_params_initialized.fill_(1)
+    return X, Y, model, lik
+
+
+def _oracle_elbo(model, lik, X, Y, kind, nu, dtype_jitter):
+    sd = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in
+          list(model.named_parameters()) + [("lik." + k, v) for k, v in lik.named_parameters()]}
+    b = "variational_strategy.base_variational_strategy."
+    has_os = "covar_module.raw_outputscale" in sd
+    ell = gm.softplus(sd["covar_module.base_kernel.raw_lengthscale" if has_os else "covar_module.raw_lengthscale"])
+    ell = ell.reshape(ell.shape[0], -1)
+    osc = gm.softplus(sd["covar_module.raw_outputscale"]) if has_os else None
+    F = sd["lik.task_noise_covar_factor"]
+    noise_diag = (F * F).sum(-1) + gm.softplus(sd["lik.raw_noise"]).reshape(()) + 1e-4
+    val = ov.variational_elbo(kind, X.double(), Y.double(), sd[b + "inducing_points"], ell,
+                              sd[b + "_variational_distribution.variational_mean"],
+                              sd[b + "_variational_distribution.chol_variational_covar"],
+                              sd["variational_strategy.lmc_coefficients"], noise_diag,
+                              task_means=sd["variational_strategy.output_mean_module.raw_constant"],
+                              nu=nu, outputscale=osc, jitter=dtype_jitter, num_data=X.shape[0])
+    return val, sd
+
+
+@pytest.mark.parametrize("kernel,oscale", [("RBFKernel", False), ("MaternKernel", True)])
+def test_elbo_and_all_gradients_fp64(plmc, kernel, oscale):
+    n, d, p, q = 150, 3, 4, 2
+    X, Y, model, lik = _build(plmc, n, d, p, q, kernel, oscale, torch.float64)
+    kind, nu = ("rbf", 2.5) if kernel == "RBFKernel" else ("matern", 2.5)
+    ref, sd = _oracle_elbo(model, lik, X, Y, kind, nu, 1e-6)
+    ref.backward()
+    model, lik = model.to(DEV), lik.to(DEV)
+    model.train(); lik.train()
+    mll = plmc.VariationalELBO(lik, model, num_data=n)
+    out = mll(model(X.to(DEV)), Y.to(DEV))
+    out.backward()
+    assert abs(float(out) - float(ref)) < 1e-9 * abs(float(ref)), (float(out), float(ref))
+    named = dict(list(model.named_parameters()) + [("lik." + k, v) for k, v in lik.named_parameters()])
+    for name, leaf in sd.items():
+        if leaf.grad is None:                       # unused by the ELBO (e.g. raw_task_noises does not exist for rank>0)
+            continue
+        got = named[name].grad
+        assert got is not None, name
+        ref_g = leaf.grad
+        if name.endswith("chol_variational_covar"):
+            got, ref_g = got.cpu().tril(), ref_g.tril()
+        assert torch.allclose(got.cpu(), ref_g, rtol=2e-5, atol=1e-8), (name, (got.cpu() - ref_g).abs().max())
+    assert named["variational_strategy.base_variational_strategy.inducing_points"].grad.abs().max() > 0
+
+
+def test_elbo_fp32_config4_shape(plmc):
+    """Scaled-down BASELINE config 4 (16 tasks, q = 8, Cholesky variational distribution), fp32:
+    ELBO within 1e-4 relative of the fp64 oracle evaluated at the same (fp32-rounded) parameters."""
+    n, d, p, q = 600, 8, 16, 8
+    X, Y, model, lik = _build(plmc, n, d, p, q, "RBFKernel", False, torch.float32, seed=3)
+    ref, _ = _oracle_elbo(model, lik, X, Y, "rbf", 2.5, 1e-4)
+    model, lik = model.to(DEV), lik.to(DEV)
+    out = plmc.VariationalELBO(lik, model, num_data=n)(model(X.to(DEV)), Y.to(DEV))
+    assert abs(float(out) - float(ref)) < 1e-4 * abs(float(ref)), (float(out), float(ref))
+    model.eval(); lik.eval()
+    with torch.no_grad():
+        pred = lik(model(X[:50].to(DEV)))
+    assert pred.mean.shape == (50, p) and bool((pred.variance > 0).all())
