@@ -115,11 +115,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PLMC_DIST_BACKEND=gloo is a rehearsal aid: several ranks sharing ONE GPU (RCCL refuses duplicate
+    # devices) still exercise the sharded step end to end; the measured runs use "nccl" (= RCCL).
+    backend = os.environ.get("PLMC_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import projectedlmc as plmc
     from projectedlmc import _hip, parallel
@@ -217,6 +224,18 @@ def main():
                                "frac": ach / peak, "traffic": None,
                                "avg_launch_ms": s["ms"] / s["launches"], "launches": s["launches"],
                                "flops_per_launch": s["flops"] / s["launches"]}
+            # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE cannot be read from inside
+            # the process: they come from the committed rocprofv3 --pmc passes of this same command)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                kname = {"k_trail": "k_update<float>", "k_kinv_grad": "k_kinv_grad<float, 8>"}.get(dom, dom + "<float>")
+                if world == 1 and kname in pmc["kernels"]:
+                    res["roofline"]["traffic"] = pmc["kernels"][kname]["hbm_bytes_corrected"]
+                    res["roofline"]["traffic_note"] = ("bytes/launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/"
+                                                       "r01_pmc_traffic.json; algorithmic tile traffic/launch = %.3g"
+                                                       % (s["bytes"] / s["launches"]))
+            except Exception:
+                pass
             tot_ms = sum(v["ms"] for v in stats.values())
             res["kernels"] = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
                                   "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["flops"] > 0 and v["ms"] > 0 else None,

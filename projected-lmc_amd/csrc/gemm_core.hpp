@@ -138,6 +138,33 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
   }
 }
 
+// XCD-aware enumeration of the upper-triangular tile set {(ib, jb): ib <= jb < m} of `nlat` matrices.
+// Tiles are grouped in 8 x 8 super-blocks (64 tiles that share 8 + 8 operand strips); super-blocks
+// are ordered by decreasing K-depth (jb ascending) and dealt round-robin to the 8 XCDs; workgroup w is
+// observed to land on XCD w % 8 (MI355X_MICROARCH.md "Workgroup dispatch" -- speed only, never
+// correctness), so the 64 tiles of a super-block stream their strips through ONE L2.
+// Launch with grid = xcd_tri_grid(m, nlat) workgroups; returns false for padding / dead tiles.
+__host__ __device__ inline int xcd_tri_grid(int m, int nlat) {
+  const int M = (m + 7) / 8, G = nlat * (M * (M + 1) / 2);
+  return 8 * ((G + 7) / 8) * 64;
+}
+__device__ __forceinline__ bool xcd_tri_decode(int w, int m, int nlat, int &lat, int &ib, int &jb) {
+  const int M = (m + 7) / 8, NSB = M * (M + 1) / 2, G = nlat * NSB;
+  const int xcd = w & 7, slot = w >> 3;
+  const int g = xcd + 8 * (slot >> 6);
+  if (g >= G) return false;
+  lat = g / NSB;
+  const int k = g - lat * NSB;
+  int JB = (int)((sqrtf(8.0f * (float)k + 1.0f) - 1.0f) * 0.5f);
+  while ((JB + 1) * (JB + 2) / 2 <= k) ++JB;
+  while (JB * (JB + 1) / 2 > k) --JB;
+  const int IB = k - JB * (JB + 1) / 2;
+  const int t = slot & 63;
+  ib = IB * 8 + (t >> 3);
+  jb = JB * 8 + (t & 7);
+  return ib <= jb && jb < m;
+}
+
 // C[tile] = acc (plain store of the 128x128 tile at Cg, leading dimension ldc).
 template <typename T>
 __device__ __forceinline__ void tile_store(const Acc<T> &acc, T *Cg, int64_t ldc) {

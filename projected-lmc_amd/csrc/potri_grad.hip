@@ -21,11 +21,11 @@ __global__ __launch_bounds__(NTHREADS) void k_kinv_grad(int kind, const T *__res
                                                          const T *__restrict__ X, int n, int d,
                                                          const T *__restrict__ ell, const T *__restrict__ oscale,
                                                          T *Kinv, int64_t ldk, int64_t strideK, T *kinv_diag,
-                                                         double *__restrict__ partials) {
-  const int jb = blockIdx.x, ib = blockIdx.y, lat = blockIdx.z;
-  if (jb < ib) return;
-  __shared__ __align__(16) T smem[tile_smem_elems<T>()];
+                                                         double *__restrict__ partials, int nlat) {
   const int m = (int)(n_pad / NB);
+  int lat, ib, jb;
+  if (!xcd_tri_decode(blockIdx.x, m, nlat, lat, ib, jb)) return;
+  __shared__ __align__(16) T smem[tile_smem_elems<T>()];
   const T *Wl = W + (int64_t)lat * strideW + (int64_t)jb * NB * ldw;
   Acc<T> acc;
   acc.zero();
@@ -55,10 +55,13 @@ __global__ __launch_bounds__(NTHREADS) void k_kinv_grad(int kind, const T *__res
   __syncthreads();
 
   const T os = oscale ? oscale[lat] : T(1);
-  double g[DCAP];
+  // per-lane partial sums over the lane's 64 tile elements stay in T (fp32 on the fp32 path: 64 terms,
+  // relative error ~4e-6, far inside the fp32 gradient tolerance); everything across lanes, waves and
+  // tiles is reduced in fp64.
+  T g[DCAP];
 #pragma unroll
-  for (int k = 0; k < DCAP; ++k) g[k] = 0.0;
-  double g_noise = 0.0, g_os = 0.0;
+  for (int k = 0; k < DCAP; ++k) g[k] = T(0);
+  T g_noise = T(0), g_os = T(0);
 
   // mt / nt are unrolled (static accumulator indices); the register r inside an MFMA tile is picked
   // with a select chain -- a runtime-indexed accumulator would be demoted to scratch memory, and a
@@ -94,13 +97,13 @@ __global__ __launch_bounds__(NTHREADS) void k_kinv_grad(int kind, const T *__res
           T val, base;
           kern_value_base<T>(kind, r2, val, base);
           if (gi == gj) {
-            g_noise += (double)wij;
-            g_os += (double)(wij * val);
+            g_noise += wij;
+            g_os += wij * val;
           } else {
             const T c = T(2) * wij * os * base;          // symmetric pair (i,j),(j,i)
 #pragma unroll
-            for (int k = 0; k < DCAP; ++k) g[k] += (double)(c * df2[k]);
-            g_os += (double)(T(2) * wij * val);
+            for (int k = 0; k < DCAP; ++k) g[k] += c * df2[k];
+            g_os += T(2) * wij * val;
           }
         }
       }
@@ -117,13 +120,13 @@ __global__ __launch_bounds__(NTHREADS) void k_kinv_grad(int kind, const T *__res
   };
 #pragma unroll
   for (int k = 0; k < DCAP; ++k) {
-    double s = wave_sum(g[k]);
+    double s = wave_sum((double)g[k]);
     if (lane == 0) red[wave * GP + k] = s;
   }
   {
-    double s = wave_sum(g_noise);
+    double s = wave_sum((double)g_noise);
     if (lane == 0) red[wave * GP + MAX_DIM] = s;
-    s = wave_sum(g_os);
+    s = wave_sum((double)g_os);
     if (lane == 0) red[wave * GP + MAX_DIM + 1] = s;
   }
   __syncthreads();
@@ -176,11 +179,11 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
   PLMC_REQUIRE(aligned16(W), "unaligned W");
   hipStream_t st = (hipStream_t)stream;
   const int m = (int)(n_pad / NB);
-  dim3 grid(m, m, q), block(NTHREADS);
+  dim3 grid(xcd_tri_grid(m, q)), block(NTHREADS);
   double *part = reinterpret_cast<double *>(partials);
 #define PLMC_LAUNCH_KG(DC)                                                                                          \
   hipLaunchKernelGGL((k_kinv_grad<T, DC>), grid, block, 0, st, kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell,   \
-                     oscale, Kinv, ldk, strideK, kinv_diag, part)
+                     oscale, Kinv, ldk, strideK, kinv_diag, part, q)
   {
     const double np = (double)n_pad;
     ProfScope ps(PK_KINV_GRAD, st, q * np * np * np / 3.0, q * (np * np / 2) * sizeof(T));

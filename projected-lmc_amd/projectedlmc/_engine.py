@@ -177,6 +177,33 @@ def exact_latent_log_prob(kind, X, ell, oscale, noise, y):
     return ExactLatentLogProb.apply(X, ell, oscale, noise, y, kind)
 
 
+def exact_loo(kind, X, ell, oscale, noise, y):
+    """Leave-one-out moments of q independent exact GPs sharing the factorisation the MLL uses
+    (reference: compute_loo, projected_lmc.py:371-436, 1108-1119):
+        sigma2_i = 1 / [Khat^-1]_ii ,   (y - mu_loo)_i = [Khat^-1 y]_i * sigma2_i .
+    diag(Khat^-1) is a by-product of the fused K^-1 kernel (`kinv_diag` output).  Returns (q,n),(q,n)."""
+    _hip.require_device(X, ell, noise, y)
+    L = _hip.lib()
+    dt, dev = y.dtype, y.device
+    q, n = y.shape
+    d = X.shape[1]
+    Xc, ellc, osc, nzc, yc = (_contig(t, dt) for t in (X, ell, oscale, noise, y))
+    ws = get_workspace(n, q, 1, dt, dev, True)
+    st = _hip.stream_ptr(dev)
+    factorize_checked(kind, Xc, ellc, osc, nzc, yc.reshape(q, 1, n), ws)
+    L.call("plmc_extract_col", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, 0, _hip.ptr(ws.z),
+           _hip.ptr(ws.quad), q, st)
+    L.call("plmc_wt_matvec", dt, _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.z),
+           _hip.ptr(ws.alpha), q, st)
+    grad = torch.empty(q, d + 2, dtype=torch.float64, device=dev)
+    kd = torch.empty(q, ws.n_pad, dtype=dt, device=dev)
+    L.call("plmc_kinv_grad", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.alpha),
+           _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad), None, 0, 0, _hip.ptr(kd),
+           _hip.ptr(ws.partials), q, st)
+    sigma2 = 1.0 / kd[:, :n]
+    return sigma2, ws.alpha[:, :n] * sigma2
+
+
 def exact_posterior(kind, X, ell, oscale, noise, y, Xs, full_cov=False):
     """Posterior of q zero-mean GPs at Xs from ONE augmented factorization [Khat | y | K*^T]:
     with v = U^-T k*, z = U^-T y:  mean = v^T z,  cov = K** - v^T v.

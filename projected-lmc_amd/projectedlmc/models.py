@@ -227,6 +227,27 @@ class ExactGPModel(ExactGP):
             return MultivariateNormal(mean[0], cov[0])
         return MultivariateNormal(mean, cov)
 
+    def compute_loo(self, output=None, complex_mean=False, eps=1e-6):
+        """Leave-one-out variances and residuals (projected_lmc.py:371-436): returns
+        (sigma2, y - mu_loo), shaped like train_y (n,) or (n, n_tasks).  Shares the blocked sweep with
+        the MLL; diag(Khat^-1) comes out of the fused K^-1 kernel.  `complex_mean` (basis-function
+        means) is not supported."""
+        if complex_mean:
+            raise ValueError("A complex mean treatment was required, but the model mean function doesn't allow it !")
+        tx = self.train_inputs[0]
+        lazy = self.covar_module(tx)
+        lik = self.likelihood
+        if self.batch_lik:
+            noise = lik.noise.reshape(-1).clamp_min(eps) if self.n_tasks == 1 else lik.noise.reshape(-1)
+        else:
+            noise = torch.diagonal(lik.task_noise_matrix()).reshape(-1)
+        resid = self._latent_targets() - self.mean_module(tx).reshape(self.n_tasks, -1)
+        with torch.no_grad():
+            s2, r = _engine.exact_loo(lazy.kind, lazy.x1, lazy.ell, lazy.oscale, noise.to(lazy.ell.dtype), resid)
+        if self.train_targets.dim() == 1:
+            return s2[0], r[0]
+        return s2.T, r.T
+
     # -- inspection helpers (projected_lmc.py:324-365)
     def _base(self):
         cm = self.covar_module

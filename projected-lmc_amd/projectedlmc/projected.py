@@ -244,6 +244,17 @@ class ProjectedGPModel(ExactGPModel):
         return _engine.exact_posterior(lazy.kind, lazy.x1, ell, osc, noise, ytil, self.covar_module.select(x),
                                        full_cov=full_cov)
 
+    def compute_loo(self, output=None):
+        """LOO moments of the q latent GPs on the projected data, (n x q) each
+        (projected_lmc.py:1108-1119)."""
+        tx = self.train_inputs[0]
+        lazy = self.covar_module(tx)
+        with torch.no_grad():
+            ytil = self.project_data(self.train_y)
+            s2, r = _engine.exact_loo(lazy.kind, lazy.x1, lazy.ell, lazy.oscale,
+                                      self.projected_noise().to(lazy.ell.dtype), ytil)
+        return s2.T, r.T
+
     def compute_latent_distrib(self, x, full_cov=True, **kwargs):
         """Posterior of the latent processes at x, mean (q x n) (projected_lmc.py:1093-1106)."""
         if self.training:
