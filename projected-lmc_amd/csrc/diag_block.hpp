@@ -34,26 +34,39 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
   return __builtin_bit_cast(double, r);
 }
 
-// One wave: factor + invert the 16 x 16 sub-block s held in LDS.  Returns through lacc/bad.
+// 1/sqrt(x) on the serial pivot path: hardware v_rsq seed + Newton steps (y <- y (1.5 - 0.5 x y^2))
+// instead of the ~40-instruction IEEE sqrt + divide expansion; result is within ~1 ulp.
+__device__ __forceinline__ float rsqrt_refined(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  return y * (1.5f - 0.5f * x * y * y);
+}
+__device__ __forceinline__ double rsqrt_refined(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y * (1.5 - 0.5 * x * y * y);
+}
+
+// One wave: factor + invert the 16 x 16 sub-block s held in LDS.  Branch-free: every lane runs the
+// same instruction stream; loads / stores that do not apply to a lane are redirected to a dummy LDS
+// slot (an exec-masked branch per element costs ~10 instructions on the serial path).  A non-positive
+// pivot turns into NaN/inf here and is detected from the stored diagonal afterwards.
 template <typename T>
-__device__ __forceinline__ void factor16(T *sU, T *sW, T *sPiv, int s, int lane, int gbase, int &bad) {
+__device__ __forceinline__ void factor16(T *sU, int s, int lane) {
   const int o = SB * s;
-  T x[SB];
   const int col = lane & 15;
+  const bool isU = lane < 16, isW = (lane >= 16) & (lane < 32);
+  const int dummy = 2 * TRI + NB + lane;                // private scratch word of this lane
+  T x[SB];
 #pragma unroll
   for (int i = 0; i < SB; ++i) {
-    T v = T(0);
-    if (lane < 16) { if (i <= col) v = sU[rowU(o + i) + o + col]; }
-    else if (lane < 32) { v = (i == col) ? T(1) : T(0); }
-    x[i] = v;
+    const bool vu = isU & (i <= col);
+    const T v = sU[vu ? rowU(o + i) + o + col : dummy];
+    x[i] = vu ? v : ((isW & (i == col)) ? T(1) : T(0));
   }
 #pragma unroll
   for (int k = 0; k < SB; ++k) {
     const T piv = lane_bcast(x[k], k);
-    const bool ok = piv > T(0);
-    const T inv = ok ? T(1) / dsqrt(piv) : T(1);
-    if (lane == 0) sPiv[o + k] = ok ? piv : T(1);      // logs are taken in parallel after the sweep
-    if (!ok && !bad) bad = gbase + o + k + 1;
+    const T inv = rsqrt_refined(piv);
     const T rowk = x[k] * inv;
     x[k] = rowk;
 #pragma unroll
@@ -64,13 +77,14 @@ __device__ __forceinline__ void factor16(T *sU, T *sW, T *sPiv, int s, int lane,
   }
 #pragma unroll
   for (int i = 0; i < SB; ++i) {
-    if (lane < 16) { if (i <= col) sU[rowU(o + i) + o + col] = x[i]; }
-    else if (lane < 32) { if (i >= col) sW[rowL(o + i) + o + col] = x[i]; }
+    const bool vu = isU & (i <= col), vw = isW & (i >= col);
+    const int idx = vu ? rowU(o + i) + o + col : (vw ? TRI + rowL(o + i) + o + col : dummy);
+    sU[idx] = x[i];
   }
 }
 
 // grid (q); 256 threads.  Wout (may be null): where to store W_kk as a full lower block (ldw).
-template <typename T>
+template <typename T, int DBG = 0>
 __global__ __launch_bounds__(NTHREADS) void k_diag(T *A, int64_t lda, int64_t strideA, int kblk, T *__restrict__ Vd,
                                                    int64_t strideV, T *Wout, int64_t ldw, int64_t strideW,
                                                    double *__restrict__ logdet, int *__restrict__ info) {
@@ -78,26 +92,41 @@ __global__ __launch_bounds__(NTHREADS) void k_diag(T *A, int64_t lda, int64_t st
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T *sU = reinterpret_cast<T *>(smem_raw);
   T *sW = sU + TRI;
-  T *sPiv = sW + TRI;
   const int lat = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   T *blk = A + (int64_t)lat * strideA + (int64_t)kblk * NB * lda + (int64_t)kblk * NB;
 
-  for (int e = tid; e < NB * NB; e += NTHREADS) {
-    int i = e >> 7, j = e & 127;
-    if (j >= i) sU[rowU(i) + j] = blk[(int64_t)i * lda + j];
-    if (j <= i) sW[rowL(i) + j] = (i == j) ? T(1) : T(0);
+  // thread owns column j = tid & 127 and rows (tid >> 7) + 2 * it; the global loads are issued in groups
+  // of 8 before their LDS stores so that their latencies overlap instead of adding up
+  {
+    const int j = tid & 127, i0 = tid >> 7;
+#pragma unroll 1
+    for (int it0 = 0; it0 < 64; it0 += 8) {
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 2 * (it0 + u);
+        v[u] = (j >= i) ? blk[(int64_t)i * lda + j] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 2 * (it0 + u);
+        if (j >= i) sU[rowU(i) + j] = v[u];
+        if (j <= i) sW[rowL(i) + j] = (i == j) ? T(1) : T(0);
+      }
+    }
   }
   __syncthreads();
 
-  int bad = 0;
   const int fm = lane & 15, fk = lane >> 4;
+  // Schedule: wave 0 owns the critical path -- it updates the next 16 x 16 diagonal tile first and
+  // factors it right away, while waves 1..3 apply the rest of the rank-16 update; 2 barriers per step.
+  if (wave == 0 && !(DBG & 1)) factor16<T>(sU, 0, lane);
+  __syncthreads();
   for (int s = 0; s < NSB; ++s) {
     const int o = SB * s;
-    if (wave == 0) factor16<T>(sU, sW, sPiv, s, lane, kblk * NB, bad);
-    __syncthreads();
     // ---- (b) row panel of sub-block row s: P <- W16 * P   (7 tiles: U columns right, W columns left)
-    for (int t = wave; t < NSB - 1; t += 4) {
+    for (int t = wave; t < ((DBG & 2) ? 0 : NSB - 1); t += 4) {
       const bool isU = t < NSB - 1 - s;
       const int cb = isU ? s + 1 + t : t - (NSB - 1 - s);
       typename Tr::acc_t acc;
@@ -120,9 +149,10 @@ __global__ __launch_bounds__(NTHREADS) void k_diag(T *A, int64_t lda, int64_t st
     __syncthreads();
     // ---- (c) rank-16 update of the rows below: U tiles (t,u), s<t<=u ; W tiles (t,c), c<=s<t
     int idx = 0;
-    for (int t = s + 1; t < NSB; ++t) {
-      for (int u = t; u < NSB; ++u, ++idx) {
-        if ((idx & 3) != wave) continue;
+    for (int t = s + 1; t < ((DBG & 4) ? 0 : NSB); ++t) {
+      for (int u = t; u < NSB; ++u) {
+        const bool crit = (t == s + 1) && (u == t);        // next diagonal tile: wave 0
+        if (crit ? wave != 0 : (idx++ % 3) + 1 != wave) continue;
         typename Tr::acc_t acc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -142,8 +172,8 @@ __global__ __launch_bounds__(NTHREADS) void k_diag(T *A, int64_t lda, int64_t st
           if (t < u || fm >= row) sU[rowU(SB * t + row) + SB * u + fm] = acc[r];
         }
       }
-      for (int c = 0; c <= s; ++c, ++idx) {
-        if ((idx & 3) != wave) continue;
+      for (int c = 0; c <= s; ++c) {
+        if ((idx++ % 3) + 1 != wave) continue;
         typename Tr::acc_t acc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = sW[rowL(SB * t + Tr::acc_row(lane, r)) + SB * c + fm];
@@ -158,6 +188,7 @@ __global__ __launch_bounds__(NTHREADS) void k_diag(T *A, int64_t lda, int64_t st
         for (int r = 0; r < 4; ++r) sW[rowL(SB * t + Tr::acc_row(lane, r)) + SB * c + fm] = acc[r];
       }
     }
+    if (wave == 0 && s + 1 < NSB && !(DBG & 1)) factor16<T>(sU, s + 1, lane);
     __syncthreads();
   }
 
@@ -174,16 +205,27 @@ __global__ __launch_bounds__(NTHREADS) void k_diag(T *A, int64_t lda, int64_t st
     }
     if (wo) wo[(int64_t)i * ldw + j] = (j <= i) ? sW[rowL(i) + j] : T(0);
   }
-  // log det of the block = sum of log(pivot): one log per thread, then a fixed-order reduction
-  double lg = tid < NB ? log((double)sPiv[tid]) : 0.0;
+  // log det of the block = 2 sum log(U_ii): one log per thread, fixed-order reduction; a pivot that was
+  // not positive left NaN / inf / <= 0 on the diagonal -> report the first one through info.
+  const T udiag = tid < NB ? sU[rowU(tid) + tid] : T(1);
+  const bool okp = udiag > T(0) && udiag < T(3.0e38);
+  double lg = (tid < NB && okp) ? 2.0 * log((double)udiag) : 0.0;
+  int badi = (tid < NB && !okp) ? kblk * NB + tid + 1 : 0x7fffffff;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off, 64);
+  for (int off = 32; off > 0; off >>= 1) {
+    lg += __shfl_down(lg, off, 64);
+    const int ob = __shfl_down(badi, off, 64);
+    badi = ob < badi ? ob : badi;
+  }
   __syncthreads();
   double *red = reinterpret_cast<double *>(sU);
-  if (lane == 0) red[wave] = lg;
+  int *redb = reinterpret_cast<int *>(red + 4);
+  if (lane == 0) { red[wave] = lg; redb[wave] = badi; }
   __syncthreads();
   if (tid == 0) {
     const double lacc = red[0] + red[1];
+    int bad = redb[0] < redb[1] ? redb[0] : redb[1];
+    bad = bad == 0x7fffffff ? 0 : bad;
     if (kblk == 0) { logdet[lat] = lacc; info[lat] = bad; }
     else { logdet[lat] += lacc; if (bad && info[lat] == 0) info[lat] = bad; }
   }

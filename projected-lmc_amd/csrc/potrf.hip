@@ -142,7 +142,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const int Taug = (int)(naug_pad / NB);
   const int64_t strideV = (int64_t)m * NB * NB;
   const int64_t wcol0 = n_pad + naug_pad;
-  const size_t diag_smem = (2 * TRI + NB) * sizeof(T);
+  const size_t diag_smem = (2 * TRI + NB + 64) * sizeof(T);
   static bool attr_done[2] = {false, false};
   if (!attr_done[sizeof(T) == 8]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize,

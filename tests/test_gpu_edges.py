@@ -1,0 +1,117 @@
+"""Edge cases of the HIP path: tiny / ragged / block-aligned n, d = 1 and d = 32 (plmc_max_dim),
+many latents, p == q, odd numbers of 128-blocks (exercises the pair/look-ahead schedule), repeated
+calls with cached workspaces, and size-independent properties at a larger size."""
+import warnings
+
+import pytest
+import torch
+
+from oracle import gp_math as gm
+from oracle import projected as pj
+from _bridge import oracle_params, perturb_
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(eng, kind, okind, nu, n, d, q, seed, dtype=torch.float64, use_os=True):
+    g = torch.Generator().manual_seed(seed)
+    X = 2 * torch.rand(n, d, generator=g, dtype=torch.float64) - 1
+    y = torch.randn(q, n, generator=g, dtype=torch.float64)
+    ell = 0.4 + 0.6 * torch.rand(q, d, generator=g, dtype=torch.float64)
+    if d > 8:
+        ell = ell * (d / 4) ** 0.5
+    noise = 0.05 + 0.5 * torch.rand(q, generator=g, dtype=torch.float64)
+    osc = 0.5 + torch.rand(q, generator=g, dtype=torch.float64) if use_os else None
+    ref = gm.exact_latent_log_prob_analytic(okind, X, ell, noise, y, osc, nu)
+    f = lambda t: None if t is None else t.to(DEV, dtype)
+    ell_d, nz_d, y_d = f(ell).requires_grad_(), f(noise).requires_grad_(), f(y).requires_grad_()
+    lp = eng.exact_latent_log_prob(kind, f(X), ell_d, f(osc), nz_d, y_d)
+    lp.sum().backward()
+    return lp.detach().cpu().double(), ell_d.grad.cpu().double(), nz_d.grad.cpu().double(), y_d.grad.cpu().double(), ref
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from projectedlmc import _engine
+    assert torch.cuda.is_available()
+    return _engine
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 127, 128, 129, 255, 256, 257, 383, 384, 640, 769])
+def test_ragged_and_aligned_sizes(eng, n):
+    lp, ge, gn, gy, ref = _run(eng, "matern52", "matern", 2.5, n, 3, 2, seed=n)
+    assert torch.allclose(lp, ref[0], rtol=1e-10)
+    assert torch.allclose(ge, ref[1], rtol=1e-7, atol=1e-9)
+    assert torch.allclose(gn, ref[2], rtol=1e-7, atol=1e-9)
+    assert torch.allclose(gy, ref[4], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("d", [1, 5, 9, 16, 21, 32])
+def test_input_dimensions(eng, d):
+    lp, ge, gn, gy, ref = _run(eng, "rbf", "rbf", 2.5, 300, d, 2, seed=d)
+    assert torch.allclose(lp, ref[0], rtol=1e-10)
+    assert torch.allclose(ge, ref[1], rtol=1e-7, atol=1e-9)
+
+
+def test_dimension_above_limit_raises(eng):
+    X = torch.zeros(10, 33, device=DEV, dtype=torch.float64)
+    with pytest.raises(ValueError, match="plmc_max_dim"):
+        eng.exact_latent_log_prob("rbf", X, torch.ones(1, 33, device=DEV, dtype=torch.float64), None,
+                                  torch.ones(1, device=DEV, dtype=torch.float64),
+                                  torch.zeros(1, 10, device=DEV, dtype=torch.float64))
+
+
+def test_many_latents_and_repeated_calls(eng):
+    for rep in range(3):                                   # cached workspace must give identical results
+        lp, ge, gn, gy, ref = _run(eng, "matern32", "matern", 1.5, 200, 2, 11, seed=5)
+        assert torch.allclose(lp, ref[0], rtol=1e-10)
+        assert torch.allclose(ge, ref[1], rtol=1e-7, atol=1e-9)
+
+
+def test_p_equals_q_projected_model():
+    import projectedlmc as plmc
+    g = torch.Generator().manual_seed(3)
+    n, d, p = 150, 2, 3
+    X = 2 * torch.rand(n, d, generator=g, dtype=torch.float64) - 1
+    Y = torch.randn(n, p, generator=g, dtype=torch.float64)
+    for kw in (dict(BDN=True, scalar_B=True, diagonal_B=True), dict(BDN=False)):
+        torch.manual_seed(0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = plmc.ProjectedGPModel(X, Y, p, p, mean_type=plmc.ZeroMean, kernel_type=plmc.RBFKernel,
+                                      init_lmc_coeffs=True, **kw)
+        m = perturb_(m.double())
+        P = oracle_params(m)
+        ref = float(pj.projected_mll(P, X, Y))
+        m = m.to(DEV)
+        m.train()
+        val = float(plmc.ProjectedLMCmll(m.likelihood, m)(m(X.to(DEV)), Y.to(DEV)))
+        assert abs(val - ref) < 1e-9 * abs(ref), (kw, val, ref)
+
+
+def test_full_size_properties_fp32(eng):
+    """At n = 4096 (too big for the dense fp64 oracle to be quick) check size-independent properties:
+    log-prob invariance under a permutation of the data points, linear scaling identity
+    logp(c y; c^2 K) = logp(y; K) - n log c, and d logp/dy = -alpha with alpha^T y = quadratic form."""
+    n, d, q = 4096, 8, 2
+    g = torch.Generator().manual_seed(0)
+    X = (2 * torch.rand(n, d, generator=g) - 1).to(DEV)
+    y = torch.randn(q, n, generator=g).to(DEV)
+    ell = torch.full((q, d), 0.8, device=DEV)
+    noise = torch.tensor([0.3, 0.6], device=DEV)
+    osc = torch.tensor([1.0, 1.0], device=DEV)
+    yg = y.clone().requires_grad_()
+    lp = eng.exact_latent_log_prob("matern52", X, ell, osc, noise, yg)
+    lp.sum().backward()
+    perm = torch.randperm(n, generator=g).to(DEV)
+    lp_perm = eng.exact_latent_log_prob("matern52", X[perm], ell, osc, noise, y[:, perm])
+    assert torch.allclose(lp.detach(), lp_perm, rtol=2e-5)
+    c = 3.0
+    lp_scaled = eng.exact_latent_log_prob("matern52", X, ell, osc * c * c, noise * c * c, y * c)
+    assert torch.allclose(lp_scaled, lp.detach() - n * torch.log(torch.tensor(c)), rtol=2e-5)
+    # Euler identity for the Gaussian log-density: y . dlogp/dy = -quad, and logp = -1/2(quad + logdet + n log 2pi)
+    quad = -(yg.grad * y).sum(-1)
+    assert bool((quad > 0).all())
+    lp_half = eng.exact_latent_log_prob("matern52", X, ell, osc, noise, 0.5 * y)
+    assert torch.allclose(lp_half - lp.detach(), 0.5 * quad * (1 - 0.25), rtol=1e-3)
