@@ -16,6 +16,7 @@ from .models import (ExactGPModel, handle_covar_, init_lmc_coefficients, ScalarP
                      PositiveDiagonalParam, UpperTriangularParam, LowerTriangularParam)
 from .projected import LMCMixingMatrix, ProjectedGPModel, ProjectedLMCmll  # noqa: F401
 from .multitask import MultitaskGPModel  # noqa: F401
+from .sgpr import InducingPointKernel  # noqa: F401
 from . import variational  # noqa: F401
 from .variational import (VariationalMultitaskGPModel, CustomLMCVariationalStrategy, VariationalELBO,  # noqa: F401
                           CholeskyVariationalDistribution, VariationalStrategy, LMCVariationalStrategy)

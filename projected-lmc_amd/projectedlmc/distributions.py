@@ -98,6 +98,9 @@ class MultivariateNormal:
         (the call the reference makes at projected_lmc.py:1201)."""
         c = self._covar
         diff = value - self.loc
+        if hasattr(c, "log_prob_batch"):                       # SGPR / Nystrom prior (sgpr.py)
+            q = c.ell.shape[0]
+            return c.log_prob_batch(diff.reshape(q, -1)).reshape(self.batch_shape)
         if isinstance(c, LazyKernel):
             from . import _engine
             if c.noise is None:

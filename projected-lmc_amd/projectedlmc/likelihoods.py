@@ -61,7 +61,7 @@ class GaussianLikelihood(_GaussianLikelihoodBase):
     def forward(self, function_dist, *params, **kwargs):
         c = function_dist.lazy_covariance_matrix
         noise = self.noise.reshape(-1)
-        if isinstance(c, LazyKernel):
+        if isinstance(c, LazyKernel) or hasattr(c, "log_prob_batch"):
             new = c.add_noise(noise.to(c.ell.dtype))
         elif torch.is_tensor(c):
             eye = torch.eye(c.shape[-1], dtype=c.dtype, device=c.device)

@@ -16,6 +16,14 @@ class MarginalLogLikelihood(torch.nn.Module):
         self.model = model
 
     def _add_other_terms(self, res, params):
+        """Added loss terms registered by the model's modules (the SGPR trace term of
+        InducingPointKernel [gpytorch-knowledge]); priors are out of scope."""
+        for mod in self.model.modules():
+            fn = getattr(mod, "added_loss_term", None)
+            if fn is not None:
+                term = fn()
+                if term is not None:
+                    res = res + term.reshape(res.shape)
         return res
 
 

@@ -188,7 +188,9 @@ class ExactGPModel(ExactGP):
                                           prior_width=prior_width, outputscales=outputscales, n_funcs=n_tasks,
                                           ker_kwargs=ker_kwargs)
         if n_inducing_points is not None:
-            raise NotImplementedError("inducing-point (SGPR) kernels are a SURVEY.md 8f 'next' row")
+            from .sgpr import InducingPointKernel
+            self.covar_module = InducingPointKernel(self.covar_module, torch.randn(n_inducing_points, self.dim),
+                                                    likelihood)
 
     def forward(self, x):
         mean_x = self.mean_module(x)
@@ -216,11 +218,17 @@ class ExactGPModel(ExactGP):
         prior_mean = self.mean_module(tx).reshape(self.n_tasks, -1)
         resid = self._latent_targets() - prior_mean
         xs = self.covar_module.select(x)
+        if hasattr(lazy, "log_prob_batch"):                    # SGPR predictive moments (sgpr.py)
+            with torch.no_grad():
+                mean, v = lazy.add_noise(noise.detach().to(lazy.ell.dtype)).posterior(resid.detach(), xs)
+            return self._wrap_posterior(mean + self.mean_module(x).reshape(self.n_tasks, -1), torch.diag_embed(v))
         mean, v = _engine.exact_posterior(lazy.kind, lazy.x1, lazy.ell.detach(),
                                           None if lazy.oscale is None else lazy.oscale.detach(),
                                           noise.detach().to(lazy.ell.dtype), resid.detach(), xs, full_cov=full_cov)
         mean = mean + self.mean_module(x).reshape(self.n_tasks, -1)
-        cov = v if full_cov else torch.diag_embed(v)
+        return self._wrap_posterior(mean, v if full_cov else torch.diag_embed(v))
+
+    def _wrap_posterior(self, mean, cov):
         if not self.batch_lik and self.n_tasks > 1:
             return MultitaskMultivariateNormal.from_batch_mvn(MultivariateNormal(mean, cov))
         if self.n_tasks == 1 and self.train_targets.dim() == 1:

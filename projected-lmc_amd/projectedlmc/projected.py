@@ -235,6 +235,12 @@ class ProjectedGPModel(ExactGPModel):
         tx = self.train_inputs[0]
         lazy = self.covar_module(tx)
         ytil = self.project_data(self.train_y).detach()
+        if hasattr(lazy, "log_prob_batch"):                    # SGPR latents (n_inducing_points)
+            if full_cov:
+                raise NotImplementedError("full_cov with inducing-point latents")
+            with torch.no_grad():
+                noisy = lazy.add_noise(self.projected_noise().detach().to(lazy.ell.dtype))
+                return noisy.posterior(ytil, self.covar_module.select(x))
         ids = self.latent_ids
         ell, osc, noise = lazy.ell.detach(), lazy.oscale, self.projected_noise().detach().to(lazy.ell.dtype)
         osc = None if osc is None else osc.detach()
