@@ -138,6 +138,52 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
   }
 }
 
+// Coalesced epilogue: C[tile] (+)= acc through LDS.  The MFMA accumulator layout gives each lane 4-byte
+// pieces of 64-byte row segments (64 scalar loads + 64 scalar stores per lane for a read-modify-write);
+// transposing the tile through LDS in two 64-row halves turns that into 16-byte accesses of full
+// 512-byte rows (8 + 8 per lane for fp32).  `smem` = the mainloop's staging buffer (free after its
+// final barrier; needs 64 x 132 elements).  All 256 threads must call it.
+template <typename T, bool ADD>
+__device__ __forceinline__ void tile_writeback(const Acc<T> &acc, T *Cg, int64_t ldc, T *smem) {
+  using vec_t = typename Traits<T>::vec_t;
+  constexpr int EPV = Traits<T>::EPV;
+  constexpr int LDW = 132;
+  constexpr int CPR = 128 / EPV;                       // 16-byte chunks per row
+  constexpr int NCH = 64 * CPR / NTHREADS;             // chunks per thread per half (8 fp32 / 16 fp64)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();                         // previous half fully read back
+    if (wm == half) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = mt * 16 + Traits<T>::acc_row(lane, r);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) smem[row * LDW + wn * 64 + nt * 16 + (lane & 15)] = acc.v[mt][nt][r];
+        }
+    }
+    __syncthreads();
+    vec_t v[NCH];
+    if (ADD) {
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        const int c = tid + h * NTHREADS, row = c / CPR, col = (c % CPR) * EPV;
+        v[h] = *reinterpret_cast<const vec_t *>(Cg + (int64_t)(half * 64 + row) * ldc + col);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      const int c = tid + h * NTHREADS, row = c / CPR, col = (c % CPR) * EPV;
+      const vec_t s = *reinterpret_cast<const vec_t *>(smem + row * LDW + col);
+      vec_t o = ADD ? v[h] + s : s;
+      *reinterpret_cast<vec_t *>(Cg + (int64_t)(half * 64 + row) * ldc + col) = o;
+    }
+  }
+}
+
 // XCD-aware enumeration of the upper-triangular tile set {(ib, jb): ib <= jb < m} of `nlat` matrices.
 // Tiles are grouped in 8 x 8 super-blocks (64 tiles that share 8 + 8 operand strips); super-blocks
 // are ordered by decreasing K-depth (jb ascending) and dealt round-robin to the 8 XCDs; workgroup w is

@@ -80,8 +80,8 @@ __global__ __launch_bounds__(NTHREADS) void k_update(T *A, int64_t lda, int64_t 
   acc.zero();
   tile_mainloop<T, true>(acc, Prow + (int64_t)ib * NB, lda, Prow + col0, lda, depth, smem);
   T *C = Al + (int64_t)ib * NB * lda + col0;
-  if (first) tile_store<T>(acc, C, lda);
-  else tile_add_store<T>(acc, C, lda);
+  if (first) tile_writeback<T, false>(acc, C, lda, smem);
+  else tile_writeback<T, true>(acc, C, lda, smem);
 }
 
 // ----------------------------------------------------------------------------------------------

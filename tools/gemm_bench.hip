@@ -21,6 +21,26 @@ __global__ __launch_bounds__(256) void k_v0(const float *A, const float *B, floa
   tile_store<float>(acc, C + (int64_t)bi * 128 * N + bj * 128, N);
 }
 
+// ---------------- V0r: product engine, C -= A^T B (read-modify-write epilogue, as the sweep's k_update)
+__global__ __launch_bounds__(256) void k_v0_rmw(const float *A, const float *B, float *C, int M, int N, int K) {
+  __shared__ __align__(16) float smem[tile_smem_elems<float>()];
+  Acc<float> acc; acc.zero();
+  int bi = blockIdx.y, bj = blockIdx.x;
+  tile_mainloop<float, true>(acc, A + bi * 128, M, B + bj * 128, N, K, smem);
+  tile_add_store<float>(acc, C + (int64_t)bi * 128 * N + bj * 128, N);
+}
+
+// ---------------- V0n: product engine, epilogue suppressed (one element per lane stored) -> prologue cost only
+__global__ __launch_bounds__(256) void k_v0_nostore(const float *A, const float *B, float *C, int M, int N, int K) {
+  __shared__ __align__(16) float smem[tile_smem_elems<float>()];
+  Acc<float> acc; acc.zero();
+  int bi = blockIdx.y, bj = blockIdx.x;
+  tile_mainloop<float, true>(acc, A + bi * 128, M, B + bj * 128, N, K, smem);
+  float s = 0.f;
+  for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) for (int r = 0; r < 4; ++r) s += acc.v[a][b][r];
+  C[((int64_t)bi * 128 + (threadIdx.x >> 1)) * N + bj * 128 + (threadIdx.x & 1)] = s;
+}
+
 // ---------------- V1: 32x32x2 MFMA, register staging, unpadded LDS [BK][128]
 template <int BKT>
 __global__ __launch_bounds__(256) void k_v1(const float *__restrict__ A, const float *__restrict__ B, float *C, int M, int N, int K) {
@@ -164,6 +184,20 @@ int main(int argc, char **argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= R;
     printf("%-28s %8.3f ms  %7.2f TFLOP/s\n", name, ms, 2.0 * M * N * K / ms / 1e9); fflush(stdout);
   };
+  {  // the regime of the sweep: short K, RMW epilogue (timed without the correctness check)
+    hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_v0_rmw, grid, block, 0, 0, dA, dB, dC, M, N, K);
+    CK(hipEventRecord(a0)); for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(k_v0_rmw, grid, block, 0, 0, dA, dB, dC, M, N, K);
+    CK(hipEventRecord(a1)); CK(hipEventSynchronize(a1)); float ms; CK(hipEventElapsedTime(&ms, a0, a1)); ms /= 10;
+    printf("v0 RMW epilogue K=%d          %8.3f ms  %7.2f TFLOP/s\n", K, ms, 2.0 * M * N * K / ms / 1e9);
+  }
+  {
+    hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_v0_nostore, grid, block, 0, 0, dA, dB, dC, M, N, K);
+    CK(hipEventRecord(a0)); for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(k_v0_nostore, grid, block, 0, 0, dA, dB, dC, M, N, K);
+    CK(hipEventRecord(a1)); CK(hipEventSynchronize(a1)); float ms; CK(hipEventElapsedTime(&ms, a0, a1)); ms /= 10;
+    printf("v0 no-store epilogue K=%d     %8.3f ms  %7.2f TFLOP/s\n", K, ms, 2.0 * M * N * K / ms / 1e9);
+  }
   timeit("v0 16x16x4 BK16 reg", [&] { hipLaunchKernelGGL(k_v0, grid, block, 0, 0, dA, dB, dC, M, N, K); });
   timeit("v1 32x32x2 BK16 reg", [&] { hipLaunchKernelGGL(k_v1<16>, grid, block, 0, 0, dA, dB, dC, M, N, K); });
   timeit("v1 32x32x2 BK32 reg", [&] { hipLaunchKernelGGL(k_v1<32>, grid, block, 0, 0, dA, dB, dC, M, N, K); });
