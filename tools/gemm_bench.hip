@@ -41,6 +41,29 @@ __global__ __launch_bounds__(256) void k_v0_nostore(const float *A, const float 
   C[((int64_t)bi * 128 + (threadIdx.x >> 1)) * N + bj * 128 + (threadIdx.x & 1)] = s;
 }
 
+// ---------------- V0s: as V0r, but the first 1024 workgroups start staggered (0, 1/4, 1/2, 3/4 of a tile
+// time for the 4 co-resident workgroups of a CU) so that prologues/epilogues stop coinciding.
+__global__ __launch_bounds__(256) void k_v0_rmw_stagger(const float *A, const float *B, float *C, int M, int N, int K, int ticks) {
+  __shared__ __align__(16) float smem[tile_smem_elems<float>()];
+  const int w = blockIdx.y * gridDim.x + blockIdx.x;
+  if (w < 1024) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long wait = (unsigned long long)(w >> 8) * ticks;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
+  Acc<float> acc; acc.zero();
+  int bi = blockIdx.y, bj = blockIdx.x;
+  tile_mainloop<float, true>(acc, A + bi * 128, M, B + bj * 128, N, K, smem);
+  tile_writeback<float, true>(acc, C + (int64_t)bi * 128 * N + bj * 128, N, smem);
+}
+__global__ __launch_bounds__(256) void k_v0_rmw_wb(const float *A, const float *B, float *C, int M, int N, int K) {
+  __shared__ __align__(16) float smem[tile_smem_elems<float>()];
+  Acc<float> acc; acc.zero();
+  int bi = blockIdx.y, bj = blockIdx.x;
+  tile_mainloop<float, true>(acc, A + bi * 128, M, B + bj * 128, N, K, smem);
+  tile_writeback<float, true>(acc, C + (int64_t)bi * 128 * N + bj * 128, N, smem);
+}
+
 // ---------------- V1: 32x32x2 MFMA, register staging, unpadded LDS [BK][128]
 template <int BKT>
 __global__ __launch_bounds__(256) void k_v1(const float *__restrict__ A, const float *__restrict__ B, float *C, int M, int N, int K) {
@@ -197,6 +220,18 @@ int main(int argc, char **argv) {
     CK(hipEventRecord(a0)); for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(k_v0_nostore, grid, block, 0, 0, dA, dB, dC, M, N, K);
     CK(hipEventRecord(a1)); CK(hipEventSynchronize(a1)); float ms; CK(hipEventElapsedTime(&ms, a0, a1)); ms /= 10;
     printf("v0 no-store epilogue K=%d     %8.3f ms  %7.2f TFLOP/s\n", K, ms, 2.0 * M * N * K / ms / 1e9);
+  }
+  {
+    hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
+    auto tm = [&](const char *nm, auto launch) {
+      for (int w = 0; w < 2; ++w) launch();
+      CK(hipEventRecord(a0)); for (int r = 0; r < 10; ++r) launch();
+      CK(hipEventRecord(a1)); CK(hipEventSynchronize(a1)); float ms; CK(hipEventElapsedTime(&ms, a0, a1)); ms /= 10;
+      printf("%-30s %8.3f ms  %7.2f TFLOP/s\n", nm, ms, 2.0 * M * N * K / ms / 1e9); };
+    tm("v0 RMW coalesced writeback", [&] { hipLaunchKernelGGL(k_v0_rmw_wb, grid, block, 0, 0, dA, dB, dC, M, N, K); });
+    for (int ticks : {400, 800, 1600, 2400})
+      { char nm[64]; snprintf(nm, 64, "v0 RMW wb stagger %d ticks", ticks);
+        tm(nm, [&] { hipLaunchKernelGGL(k_v0_rmw_stagger, grid, block, 0, 0, dA, dB, dC, M, N, K, ticks); }); }
   }
   timeit("v0 16x16x4 BK16 reg", [&] { hipLaunchKernelGGL(k_v0, grid, block, 0, 0, dA, dB, dC, M, N, K); });
   timeit("v1 32x32x2 BK16 reg", [&] { hipLaunchKernelGGL(k_v1<16>, grid, block, 0, 0, dA, dB, dC, M, N, K); });
