@@ -99,8 +99,7 @@ class MultivariateNormal:
         c = self._covar
         diff = value - self.loc
         if hasattr(c, "log_prob_batch"):                       # SGPR / Nystrom prior (sgpr.py)
-            q = c.ell.shape[0]
-            return c.log_prob_batch(diff.reshape(q, -1)).reshape(self.batch_shape)
+            return c.log_prob_batch(diff.reshape(-1, diff.shape[-1])).reshape(self.batch_shape)
         if isinstance(c, LazyKernel):
             from . import _engine
             if c.noise is None:

@@ -18,15 +18,29 @@ def handle_covar_(kernel, dim, decomp=None, n_funcs=1, prior_scales=None, prior_
                   ker_kwargs=None):
     """Kernel factory with the reference's semantics (projected_lmc.py:107-181): an ARD kernel with
     batch_shape=[n_funcs]; wrapped in a ScaleKernel when `outputscales`.  Lengthscales start at the
-    prior mean when `prior_scales` is given (:169-179).  Additive `decomp` kernels and lengthscale
-    priors in the loss are SURVEY.md 8f "next" rows and raise NotImplementedError."""
+    prior mean when `prior_scales` is given (:169-179).  `decomp` with several groups builds the
+    additive kernel of additive.py (single-output models).  The lengthscale priors themselves are
+    not added to the loss (no BASELINE config registers any)."""
     ker_kwargs = {} if ker_kwargs is None else ker_kwargs
     if decomp is None:
         decomp = [list(range(dim))]
-    if len(decomp) > 1:
-        raise NotImplementedError("additive sub-kernel decompositions (decomp) are not built yet (SURVEY.md 8f-4)")
     if prior_scales is not None and prior_width is None:
         raise ValueError('A prior width should be provided if a prior mean is')
+    if len(decomp) > 1:
+        # k(x) = sum_g s_g k_g(x[idx_g]): every sub-kernel gets an output scale (:159-162)
+        from .additive import AdditiveKernel
+        subs = []
+        for i_ker, idx_g in enumerate(decomp):
+            kg = kernel(ard_num_dims=len(idx_g), active_dims=idx_g, lengthscale_prior=None,
+                        batch_shape=torch.Size([n_funcs]), **ker_kwargs)
+            if prior_scales is not None and kg.has_lengthscale:
+                try:
+                    sc = prior_scales[i_ker] if isinstance(prior_scales, list) else torch.as_tensor(prior_scales)[idx_g]
+                    kg.lengthscale = sc
+                except Exception:
+                    raise ValueError('Provided prior scales were of the wrong shape')
+            subs.append(_k.ScaleKernel(kg, batch_shape=torch.Size([n_funcs])))
+        return AdditiveKernel(*subs)
     idx = decomp[0]
     ker = kernel(ard_num_dims=len(idx), active_dims=idx, lengthscale_prior=None,
                  batch_shape=torch.Size([n_funcs]), **ker_kwargs)
@@ -262,11 +276,20 @@ class ExactGPModel(ExactGP):
         return cm.base_kernel if hasattr(cm, "base_kernel") else cm
 
     def lscales(self, unpacked=True):
+        cm = self.covar_module
+        if hasattr(cm, "kernels"):                                   # additive decomposition: one entry per sub-kernel
+            return [(k.base_kernel if hasattr(k, "base_kernel") else k).lengthscale.data.squeeze() for k in cm.kernels]
         scales = self._base().lengthscale.data.squeeze()
         return scales if unpacked else [scales]
 
     def outputscale(self, unpacked=False):
         n_funcs = self.n_latents if hasattr(self, "n_latents") else self.n_tasks
+        cm = self.covar_module
+        if hasattr(cm, "kernels"):
+            res = torch.zeros((n_funcs, len(cm.kernels)))
+            for i_ker, k in enumerate(cm.kernels):
+                res[:, i_ker] = k.outputscale.data.squeeze()
+            return res
         res = torch.zeros((n_funcs, 1))
-        res[:, 0] = self.covar_module.outputscale.data.squeeze()
+        res[:, 0] = cm.outputscale.data.squeeze()
         return res.squeeze() if unpacked else res
