@@ -22,6 +22,7 @@ __device__ __forceinline__ int rowL(int i) { return (i * (i + 1)) / 2; }        
 constexpr int TRI = NB * (NB + 1) / 2;
 constexpr int SB = 16;               // sub-block edge
 constexpr int NSB = NB / SB;         // 8
+constexpr int DIAG_NT = 1024;        // threads of the diagonal-block kernel
 
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
@@ -83,12 +84,13 @@ __device__ __forceinline__ void factor16(T *sU, int s, int lane) {
   }
 }
 
-// grid (q); 256 threads.  Wout (may be null): where to store W_kk as a full lower block (ldw).
-template <typename T, int DBG = 0>
-__global__ __launch_bounds__(NTHREADS) void k_diag(T *A, int64_t lda, int64_t strideA, int kblk, T *__restrict__ Vd,
+// grid (q); NT threads (DIAG_NT = 1024: 16 waves share the rank-16 updates).  Wout (may be null): where to store W_kk as a full lower block (ldw).
+template <typename T, int DBG = 0, int NT = DIAG_NT>
+__global__ __launch_bounds__(NT) void k_diag(T *A, int64_t lda, int64_t strideA, int kblk, T *__restrict__ Vd,
                                                    int64_t strideV, T *Wout, int64_t ldw, int64_t strideW,
                                                    double *__restrict__ logdet, int *__restrict__ info) {
   using Tr = Traits<T>;
+  __builtin_amdgcn_s_setprio(3);       // critical path: win issue arbitration against co-resident update tiles
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T *sU = reinterpret_cast<T *>(smem_raw);
   T *sW = sU + TRI;
@@ -99,18 +101,19 @@ __global__ __launch_bounds__(NTHREADS) void k_diag(T *A, int64_t lda, int64_t st
   // thread owns column j = tid & 127 and rows (tid >> 7) + 2 * it; the global loads are issued in groups
   // of 8 before their LDS stores so that their latencies overlap instead of adding up
   {
+    constexpr int RPP = NT / 128;                        // rows covered per pass
     const int j = tid & 127, i0 = tid >> 7;
 #pragma unroll 1
-    for (int it0 = 0; it0 < 64; it0 += 8) {
+    for (int it0 = 0; it0 < 128 / RPP; it0 += 8) {
       T v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = i0 + 2 * (it0 + u);
+        const int i = i0 + RPP * (it0 + u);
         v[u] = (j >= i) ? blk[(int64_t)i * lda + j] : T(0);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = i0 + 2 * (it0 + u);
+        const int i = i0 + RPP * (it0 + u);
         if (j >= i) sU[rowU(i) + j] = v[u];
         if (j <= i) sW[rowL(i) + j] = (i == j) ? T(1) : T(0);
       }
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(NTHREADS) void k_diag(T *A, int64_t lda, int64_t st
   for (int s = 0; s < NSB; ++s) {
     const int o = SB * s;
     // ---- (b) row panel of sub-block row s: P <- W16 * P   (7 tiles: U columns right, W columns left)
-    for (int t = wave; t < ((DBG & 2) ? 0 : NSB - 1); t += 4) {
+    for (int t = wave; t < ((DBG & 2) ? 0 : NSB - 1); t += NT / 64) {
       const bool isU = t < NSB - 1 - s;
       const int cb = isU ? s + 1 + t : t - (NSB - 1 - s);
       typename Tr::acc_t acc;
@@ -148,11 +151,14 @@ __global__ __launch_bounds__(NTHREADS) void k_diag(T *A, int64_t lda, int64_t st
     }
     __syncthreads();
     // ---- (c) rank-16 update of the rows below: U tiles (t,u), s<t<=u ; W tiles (t,c), c<=s<t
-    int idx = 0;
+    // round-robin over waves 1..NW-1 with a wrapping counter (an integer modulo per candidate tile
+    // cost more than the tile itself)
+    int rr = 0;
+    auto mine = [&]() { const bool m = (rr + 1 == wave); rr = (rr + 1 == NT / 64 - 1) ? 0 : rr + 1; return m; };
     for (int t = s + 1; t < ((DBG & 4) ? 0 : NSB); ++t) {
       for (int u = t; u < NSB; ++u) {
         const bool crit = (t == s + 1) && (u == t);        // next diagonal tile: wave 0
-        if (crit ? wave != 0 : (idx++ % 3) + 1 != wave) continue;
+        if (crit ? wave != 0 : !mine()) continue;
         typename Tr::acc_t acc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(NTHREADS) void k_diag(T *A, int64_t lda, int64_t st
         }
       }
       for (int c = 0; c <= s; ++c) {
-        if ((idx++ % 3) + 1 != wave) continue;
+        if (!mine()) continue;
         typename Tr::acc_t acc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = sW[rowL(SB * t + Tr::acc_row(lane, r)) + SB * c + fm];
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(NTHREADS) void k_diag(T *A, int64_t lda, int64_t st
   // ---- write back: U_kk (upper part), Vd = W_kk^T (full block, zeros below), optional W_kk (lower)
   T *vd = Vd + (int64_t)lat * strideV + (int64_t)kblk * NB * NB;
   T *wo = Wout ? Wout + (int64_t)lat * strideW : nullptr;
-  for (int e = tid; e < NB * NB; e += NTHREADS) {
+  for (int e = tid; e < NB * NB; e += NT) {
     int i = e >> 7, j = e & 127;
     if (j >= i) {
       blk[(int64_t)i * lda + j] = sU[rowU(i) + j];
@@ -219,11 +225,11 @@ __global__ __launch_bounds__(NTHREADS) void k_diag(T *A, int64_t lda, int64_t st
   }
   __syncthreads();
   double *red = reinterpret_cast<double *>(sU);
-  int *redb = reinterpret_cast<int *>(red + 4);
+  int *redb = reinterpret_cast<int *>(red + NT / 64);
   if (lane == 0) { red[wave] = lg; redb[wave] = badi; }
   __syncthreads();
   if (tid == 0) {
-    const double lacc = red[0] + red[1];
+    const double lacc = red[0] + red[1];                  // pivots live in threads 0..127 = waves 0, 1
     int bad = redb[0] < redb[1] ? redb[0] : redb[1];
     bad = bad == 0x7fffffff ? 0 : bad;
     if (kblk == 0) { logdet[lat] = lacc; info[lat] = bad; }

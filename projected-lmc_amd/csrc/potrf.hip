@@ -33,6 +33,7 @@ struct ColMap {
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_panel(T *A, int64_t lda, int64_t strideA, int r, ColMap cm,
                                                      const T *__restrict__ Vd, int64_t strideV) {
+  __builtin_amdgcn_s_setprio(3);       // chain kernel: ahead of the concurrently running trailing update
   __shared__ __align__(16) T smem[tile_smem_elems<T>()];
   const int lat = blockIdx.y, t = blockIdx.x;
   int64_t col0;
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(NTHREADS) void k_panel(T *A, int64_t lda, int64_t s
 //            cb == r_hi (> r_lo): first touch, only the rows of block r_hi contribute (W[r_lo][r_hi] = 0).
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_update(T *A, int64_t lda, int64_t strideA, int ib0, int r_lo, int r_hi,
-                                                      ColMap cm) {
+                                                      ColMap cm, int prio) {
+  if (prio) __builtin_amdgcn_s_setprio(3);
   const int bx = blockIdx.x, ib = ib0 + blockIdx.y, lat = blockIdx.z;
   int64_t col0;
   int kr0 = r_lo * NB, depth = (r_hi - r_lo + 1) * NB;
@@ -142,10 +144,11 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const int Taug = (int)(naug_pad / NB);
   const int64_t strideV = (int64_t)m * NB * NB;
   const int64_t wcol0 = n_pad + naug_pad;
+  constexpr int NTD = sizeof(T) == 4 ? DIAG_NT : DIAG_NT / 2;     // fp64 would spill at 1024 threads (128 VGPRs)
   const size_t diag_smem = (2 * TRI + NB + 64) * sizeof(T);
   static bool attr_done[2] = {false, false};
   if (!attr_done[sizeof(T) == 8]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<T, 0, NTD>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)diag_smem);
     attr_done[sizeof(T) == 8] = true;
   }
@@ -154,7 +157,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   auto diag = [&](int r, hipStream_t st) {
     ProfScope ps(PK_DIAG, st, q * (2.0 / 3.0) * nb3, q * 3.0 * nb * nb * esz);
     T *wout = with_inverse ? A + (int64_t)r * NB * lda + wcol0 + (int64_t)r * NB : (T *)nullptr;
-    hipLaunchKernelGGL(k_diag<T>, dim3(q), dim3(NTHREADS), diag_smem, st, A, lda, strideA, r, Vd, strideV, wout, lda,
+    hipLaunchKernelGGL((k_diag<T, 0, NTD>), dim3(q), dim3(NTD), diag_smem, st, A, lda, strideA, r, Vd, strideV, wout, lda,
                        strideA, logdet, info);
   };
   auto panel = [&](int r, hipStream_t st) {
@@ -178,7 +181,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     const double bytes = (2.0 * (tilesU + tilesA + tilesW) - (with_inverse ? nr * (r_hi - r_lo + 1) : 0.0)) * nb * nb * esz;
     ProfScope ps(PK_TRAIL, st, q * (flopsU + flopsR), q * bytes);
     hipLaunchKernelGGL(k_update<T>, dim3(cm.nU + cm.Taug + cm.nW, nrows, q), dim3(NTHREADS), 0, st, A, lda, strideA,
-                       ib0, r_lo, r_hi, cm);
+                       ib0, r_lo, r_hi, cm, nrows == 1 ? 1 : 0);
   };
 
   // One pair of block rows: factor/invert the two diagonal blocks and solve their row panels.

@@ -9,10 +9,10 @@ template <int DBG> void run(const char *name, float *A, float *Vd, double *ld, i
   size_t sm = (2 * TRI + NB + 64) * sizeof(float);
   CK(hipFuncSetAttribute((const void *)k_diag<float, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k_diag<float, DBG>), dim3(q), dim3(NTHREADS), sm, 0, A, (int64_t)128, (int64_t)128 * 128, 0, Vd, (int64_t)128 * 128, (float *)nullptr, (int64_t)0, (int64_t)0, ld, info);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k_diag<float, DBG>), dim3(q), dim3(DIAG_NT), sm, 0, A, (int64_t)128, (int64_t)128 * 128, 0, Vd, (int64_t)128 * 128, (float *)nullptr, (int64_t)0, (int64_t)0, ld, info);
   CK(hipEventRecord(e0));
   const int R = 20;
-  for (int r = 0; r < R; ++r) hipLaunchKernelGGL((k_diag<float, DBG>), dim3(q), dim3(NTHREADS), sm, 0, A, (int64_t)128, (int64_t)128 * 128, 0, Vd, (int64_t)128 * 128, (float *)nullptr, (int64_t)0, (int64_t)0, ld, info);
+  for (int r = 0; r < R; ++r) hipLaunchKernelGGL((k_diag<float, DBG>), dim3(q), dim3(DIAG_NT), sm, 0, A, (int64_t)128, (int64_t)128 * 128, 0, Vd, (int64_t)128 * 128, (float *)nullptr, (int64_t)0, (int64_t)0, ld, info);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   printf("%-34s %7.1f us per launch\n", name, 1e3 * ms / R);
