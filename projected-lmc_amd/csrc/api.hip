@@ -15,7 +15,8 @@ char *err_buf() {
 // per kernel class.  Off by default (no events, no state).
 static const char *kProfNames[PK_COUNT] = {"k_assemble", "k_write_rhs", "k_assemble_cross", "k_diag",   "k_panel",
                                            "k_trail",    "k_wdiag",     "k_trtri_row",      "k_extract_col",
-                                           "k_wt_matvec", "k_kinv_grad", "k_reduce_grad", "k_kernel_vjp"};
+                                           "k_wt_matvec", "k_kinv_grad", "k_reduce_grad", "k_kernel_vjp",
+                                           "sweep_total"};
 struct ProfRec { int id; hipEvent_t a, b; double flops, bytes; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_recs;

@@ -184,6 +184,10 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
                        ib0, r_lo, r_hi, cm, nrows == 1 ? 1 : 0);
   };
 
+  // whole-sweep bracket on the caller's stream (the per-kernel records of overlapped kernels add up to
+  // more than the wall time once the look-ahead runs the chain beside the trailing update)
+  const double npd = (double)n_pad;
+  ProfScope whole(PK_SWEEP, st, q * (with_inverse ? 2.0 : 1.0) * npd * npd * npd / 3.0, 0.0);
   // One pair of block rows: factor/invert the two diagonal blocks and solve their row panels.
   auto chain = [&](int r0, hipStream_t s) {
     diag(r0, s);
