@@ -62,9 +62,16 @@ __global__ __launch_bounds__(NTHREADS) void k_assemble(int kind, const T *__rest
         }
         v[c] = val;
       }
-      T *dst = Al + (int64_t)gi * lda + jb * NB + c0;
+      T *dst = Al + (int64_t)gi * lda + jb * NB + c0;          // 16-byte aligned: lda, NB, c0 multiples of 4
+      using vec_t = typename Traits<T>::vec_t;
+      constexpr int EPV = Traits<T>::EPV;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) dst[c] = v[c];
+      for (int c = 0; c < 4; c += EPV) {
+        vec_t o;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) o[e] = v[c + e];
+        *reinterpret_cast<vec_t *>(dst + c) = o;
+      }
     }
   }
 }

@@ -110,23 +110,50 @@ __global__ __launch_bounds__(NTHREADS) void k_extract_col(const T *__restrict__ 
   if (threadIdx.x == 0) quad[lat] = red[0];
 }
 
-// alpha[i] = sum_{l >= block(i)} W[l][i] z[l].  grid (n_pad / 64, q); 4 row groups x 64 columns.
+// alpha[i] = sum_{l >= block(i)} W[l][i] z[l].  grid (n_pad / 128, q): one workgroup per block column;
+// 8 row groups x 32 lanes x 16-byte loads (one full 512-byte row segment per row group and step,
+// 4 rows in flight per thread).  HBM-bound: reads the lower triangle of W once.
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_wt_matvec(const T *__restrict__ W, int64_t n_pad, int64_t ldw,
                                                          int64_t strideW, const T *__restrict__ z,
                                                          T *__restrict__ alpha) {
-  __shared__ double red[4][64];
+  using vec_t = typename Traits<T>::vec_t;
+  constexpr int EPV = Traits<T>::EPV;
+  constexpr int LPR = 128 / EPV;                 // lanes per row segment (32 fp32 / 64 fp64)
+  constexpr int NRG = NTHREADS / LPR;            // row groups (8 / 4)
+  __shared__ double red[NRG][NB];
   const int lat = blockIdx.y;
-  const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int64_t col = (int64_t)blockIdx.x * 64 + lane;
-  const int64_t l0 = (col / NB) * NB;
-  const T *Wl = W + (int64_t)lat * strideW;
+  const int cl = (threadIdx.x % LPR) * EPV, rg = threadIdx.x / LPR;
+  const int64_t col0 = (int64_t)blockIdx.x * NB;
+  const T *Wl = W + (int64_t)lat * strideW + col0 + cl;
   const T *zl = z + (int64_t)lat * n_pad;
-  double s = 0.0;
-  for (int64_t l = l0 + rg; l < n_pad; l += 4) s += (double)Wl[l * ldw + col] * (double)zl[l];
-  red[rg][lane] = s;
+  double s[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) s[e] = 0.0;
+  for (int64_t l = col0 + rg; l < n_pad; l += 4 * NRG) {
+    vec_t v[4];
+    T zz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t ll = l + u * NRG;
+      const bool ok = ll < n_pad;
+      v[u] = ok ? *reinterpret_cast<const vec_t *>(Wl + ll * ldw) : vec_t{};
+      zz[u] = ok ? zl[ll] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) s[e] += (double)v[u][e] * (double)zz[u];
+  }
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) red[rg][cl + e] = s[e];
   __syncthreads();
-  if (rg == 0) alpha[(int64_t)lat * n_pad + col] = (T)(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+  if (threadIdx.x < NB) {
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < NRG; ++g) t += red[g][threadIdx.x];
+    alpha[(int64_t)lat * n_pad + col0 + threadIdx.x] = (T)t;
+  }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -246,7 +273,7 @@ int wt_matvec_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, cons
   PLMC_REQUIRE(W && z && alpha, "null pointer");
   PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0, "n_pad must be a multiple of NB");
   ProfScope ps(PK_WTMV, (hipStream_t)stream, q * (double)n_pad * n_pad, q * ((double)n_pad * n_pad / 2) * sizeof(T));
-  hipLaunchKernelGGL(k_wt_matvec<T>, dim3((unsigned)(n_pad / 64), q), dim3(NTHREADS), 0, (hipStream_t)stream, W,
+  hipLaunchKernelGGL(k_wt_matvec<T>, dim3((unsigned)(n_pad / NB), q), dim3(NTHREADS), 0, (hipStream_t)stream, W,
                      n_pad, ldw, strideW, z, alpha);
   return launch_status(__func__);
 }
