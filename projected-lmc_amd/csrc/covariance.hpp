@@ -41,4 +41,20 @@ template <typename T> __device__ __forceinline__ void kern_value_base(int kind, 
   base = T(5.0 / 3.0) * (T(1) + s) * e;
 }
 
+// Gradient-epilogue variant: for fp32 the transcendental pair is taken from the hardware units
+// (v_sqrt_f32 / v_exp_f32, ~1-2 ulp) instead of the ~35-instruction IEEE expansions; the values only
+// weight a reduction whose fp32 tolerance is 1e-3, the covariance ASSEMBLY keeps the accurate forms.
+__device__ __forceinline__ void kern_value_base_fast(int kind, float r2, float &val, float &base) {
+  if (kind == K_RBF) { val = __expf(-0.5f * r2); base = val; return; }
+  const float r = __builtin_amdgcn_sqrtf(r2 > 0.f ? r2 : 0.f);
+  if (kind == K_MATERN12) { val = __expf(-r); base = r > 1e-15f ? val / r : 0.f; return; }
+  if (kind == K_MATERN32) { const float s = 1.7320508075688772f * r, e = __expf(-s); val = (1.f + s) * e; base = 3.f * e; return; }
+  const float s = 2.23606797749979f * r, e = __expf(-s);
+  val = (1.f + s + (5.0f / 3.0f) * r2) * e;
+  base = (5.0f / 3.0f) * (1.f + s) * e;
+}
+__device__ __forceinline__ void kern_value_base_fast(int kind, double r2, double &val, double &base) {
+  kern_value_base<double>(kind, r2, val, base);
+}
+
 }  // namespace plmc

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kinv_grad(int kind, const T *__res
             r2 += df2[k];
           }
           T val, base;
-          kern_value_base<T>(kind, r2, val, base);
+          kern_value_base_fast(kind, r2, val, base);
           if (gi == gj) {
             g_noise += wij;
             g_os += wij * val;
