@@ -72,8 +72,9 @@ __global__ __launch_bounds__(NTHREADS) void k_update(T *A, int64_t lda, int64_t 
   } else {
     const int cb = bx - cm.nU - cm.Taug;
     col0 = cm.wcol0 + (int64_t)cb * NB;
-    if (cb == r_lo) first = true;
-    else if (cb == r_hi) { first = true; kr0 = r_hi * NB; depth = NB; }
+    // columns that start inside the current group: W[r][cb] = 0 for r < cb, so only panel rows
+    // cb..r_hi contribute, and this is the first time the tile is touched -> plain store
+    if (cb >= r_lo) { first = true; kr0 = cb * NB; depth = (r_hi - cb + 1) * NB; }
   }
   __shared__ __align__(16) T smem[tile_smem_elems<T>()];
   T *Al = A + (int64_t)lat * strideA;
@@ -203,9 +204,12 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     const double nr = (double)nrows;
     const double tilesU = nr * (cm.nU) - nr * (nr - 1) / 2.0;                   // tiles jb >= ib
     const double flopsU = 2.0 * nb * nb * depth * (tilesU - nr / 2.0);           // diagonal tiles count half
-    const double tilesW = nr * cm.nW, tilesA = nr * Taug;
-    const double flopsR = 2.0 * nb * nb * (depth * (tilesA + tilesW) - (with_inverse && r_hi > r_lo ? nb * nr : 0.0));
-    const double bytes = (2.0 * (tilesU + tilesA + tilesW) - (with_inverse ? nr * (r_hi - r_lo + 1) : 0.0)) * nb * nb * esz;
+    const double tilesA = nr * Taug;
+    double depthW = 0.0;                                                         // summed panel depth over W columns
+    for (int cb = 0; cb < cm.nW; ++cb) depthW += (cb >= r_lo ? (r_hi - cb + 1) : (r_hi - r_lo + 1)) * nb;
+    const double flopsR = 2.0 * nb * nb * nr * (depth * Taug + depthW);
+    const int nfirst = with_inverse ? r_hi - r_lo + 1 : 0;                       // first-touch W columns: no read
+    const double bytes = (2.0 * (tilesU + tilesA + nr * cm.nW) - nr * nfirst) * nb * nb * esz;
     ProfScope ps(PK_TRAIL, st, q * (flopsU + flopsR), q * bytes);
     hipLaunchKernelGGL(k_update<T>, dim3(cm.nU + cm.Taug + cm.nW, nrows, q), dim3(NTHREADS), 0, st, A, lda, strideA,
                        ib0, r_lo, r_hi, cm, nrows == 1 ? 1 : 0);
@@ -215,42 +219,44 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // more than the wall time once the look-ahead runs the chain beside the trailing update)
   const double npd = (double)n_pad;
   ProfScope whole(PK_SWEEP, st, q * (with_inverse ? 2.0 : 1.0) * npd * npd * npd / 3.0, 0.0);
-  // One pair of block rows: factor/invert the two diagonal blocks and solve their row panels.
-  auto chain = [&](int r0, hipStream_t s) {
-    diag(r0, s);
-    panel(r0, s);
-    if (r0 + 1 < m) {
-      update(r0 + 1, 1, r0, r0, s);
-      diag(r0 + 1, s);
-      panel(r0 + 1, s);
+  // One GROUP of GRP block rows: factor/invert each diagonal block, solve its row panel, and bring the
+  // next row of the group up to date (rank-(128 j) update with the rows of the group done so far).
+  constexpr int GRP = 4;                 // the big update then has depth GRP * 128 = 512 (8 measured slower: longer chain)
+  auto chain = [&](int g0, hipStream_t s) {
+    const int g1 = g0 + GRP < m ? g0 + GRP : m;
+    for (int r = g0; r < g1; ++r) {
+      diag(r, s);
+      panel(r, s);
+      if (r + 1 < g1) update(r + 1, 1, g0, r, s);
     }
   };
-  // Look-ahead: the depth-256 update of pair K is split into the two block rows the next pair needs
-  // ("head") and the rest ("tail"); the latency-bound chain of pair K+1 runs on a helper stream
+  // Look-ahead: the depth-512 update of group K is split into the block rows the next group needs
+  // ("head") and the rest ("tail"); the latency-bound chain of group K+1 runs on a helper stream
   // concurrently with the tail.  Falls back to a single stream if the helper cannot be created.
   hipStream_t s1 = side_stream();
   hipEvent_t e_head = sync_event(0), e_chain = sync_event(1), e_entry = sync_event(2);
-  const bool la = s1 && e_head && e_chain && e_entry && m > 4;
+  const bool la = s1 && e_head && e_chain && e_entry && m > 2 * GRP;
   if (la) {
     (void)hipEventRecord(e_entry, st);
     (void)hipStreamWaitEvent(s1, e_entry, 0);
   }
   chain(0, st);
-  for (int r0 = 0; r0 + 1 < m; r0 += 2) {
-    const int r1 = r0 + 1, first = r1 + 1, nrest = m - first;
+  for (int g0 = 0; g0 < m; g0 += GRP) {
+    const int g1 = g0 + GRP < m ? g0 + GRP : m;
+    const int first = g1, nrest = m - first;
     if (nrest <= 0) break;
     if (!la) {
-      update(first, nrest, r0, r1, st);
+      update(first, nrest, g0, g1 - 1, st);
       chain(first, st);
       continue;
     }
-    const int nhead = nrest < 2 ? nrest : 2;
-    update(first, nhead, r0, r1, st);
+    const int nhead = nrest < GRP ? nrest : GRP;
+    update(first, nhead, g0, g1 - 1, st);
     (void)hipEventRecord(e_head, st);
     (void)hipStreamWaitEvent(s1, e_head, 0);
     chain(first, s1);
     (void)hipEventRecord(e_chain, s1);
-    update(first + nhead, nrest - nhead, r0, r1, st);
+    update(first + nhead, nrest - nhead, g0, g1 - 1, st);
     (void)hipStreamWaitEvent(st, e_chain, 0);
   }
   return launch_status(__func__);
