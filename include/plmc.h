@@ -190,8 +190,10 @@ int plmc_kernel_vjp_f64(int kind, const double *X1, int n1, const double *X2, in
 
 /*
  * Optional per-kernel profiler (measurement only; the reference's counterpart is the wall-clock
- * `time.time()` around its loops, experiments.py:261,284).  While enabled, every kernel launch is
- * bracketed by two hipEvents on its launch stream.  plmc_prof_collect() waits for the recorded
+ * `time.time()` around its loops, experiments.py:261,284).  While enabled, kernel launches are
+ * bracketed by two hipEvents on their launch stream: `on` = 0 none, 1 every kernel class, any other
+ * value = (bit mask of class indices) << 1, so that a timed run can bracket the few heavy kernels
+ * only (each bracket costs ~10 us of stream time, which matters on the latency-bound chain).  plmc_prof_collect() waits for the recorded
  * events, then returns per kernel class (index < plmc_prof_kernels(), name plmc_prof_name(i)):
  * total milliseconds, number of launches, and the ALGORITHMIC flops / bytes of those launches;
  * it clears the record.  This is the only process-global state in the library.

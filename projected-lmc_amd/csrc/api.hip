@@ -16,9 +16,9 @@ char *err_buf() {
 static const char *kProfNames[PK_COUNT] = {"k_assemble", "k_write_rhs", "k_assemble_cross", "k_diag",   "k_panel",
                                            "k_trail",    "k_wdiag",     "k_trtri_row",      "k_extract_col",
                                            "k_wt_matvec", "k_kinv_grad", "k_reduce_grad", "k_kernel_vjp",
-                                           "sweep_total"};
+                                           "sweep_total", "k_trail_row"};
 struct ProfRec { int id; hipEvent_t a, b; double flops, bytes; };
-static bool g_prof_on = false;
+static unsigned g_prof_mask = 0;          // bit i: bracket kernel class i
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_free;
 
@@ -44,6 +44,24 @@ hipStream_t side_stream() {
   }
   return g_side[dev];
 }
+// Stream for the big trailing updates with a few CUs masked out: those CUs stay free for the
+// latency-bound chain kernels (a diagonal-block workgroup needs 66 KB of LDS and 16 wave slots, which a CU
+// busy with update tiles never has free at once).  Speed only; nullptr -> caller falls back.
+static hipStream_t g_tail[64] = {nullptr};
+hipStream_t tail_stream(int reserve_cus) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!g_tail[dev]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
+    const int ncu = prop.multiProcessorCount, nw = (ncu + 31) / 32;
+    if (ncu <= 2 * reserve_cus) return nullptr;
+    std::vector<uint32_t> mask(nw, 0xffffffffu);
+    for (int c = 0; c < reserve_cus; ++c) mask[c / 32] &= ~(1u << (c % 32));
+    if (hipExtStreamCreateWithCUMask(&g_tail[dev], (uint32_t)nw, mask.data()) != hipSuccess) g_tail[dev] = nullptr;
+  }
+  return g_tail[dev];
+}
 hipEvent_t sync_event(int idx) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
@@ -53,7 +71,7 @@ hipEvent_t sync_event(int idx) {
 }
 
 ProfScope::ProfScope(int id, hipStream_t st, double flops, double bytes) : idx_(-1), st_(st) {
-  if (!g_prof_on || g_recs.size() >= (1u << 20)) return;
+  if (!((g_prof_mask >> id) & 1u) || g_recs.size() >= (1u << 20)) return;
   ProfRec r{id, get_event(), get_event(), flops, bytes};
   if (!r.a || !r.b) return;
   (void)hipEventRecord(r.a, st);
@@ -73,9 +91,9 @@ int plmc_max_dim(void) { return plmc::MAX_DIM; }
 const char *plmc_last_error(void) { return plmc::err_buf(); }
 
 int plmc_prof_enable(int on) {
-  int prev = plmc::g_prof_on;
-  plmc::g_prof_on = on != 0;
-  return prev;
+  const unsigned prev = plmc::g_prof_mask, all = (1u << plmc::PK_COUNT) - 1u;
+  plmc::g_prof_mask = on == 0 ? 0u : (on == 1 ? all : ((unsigned)on >> 1) & all);
+  return prev == 0 ? 0 : (prev == all ? 1 : (int)(prev << 1));
 }
 int plmc_prof_kernels(void) { return plmc::PK_COUNT; }
 const char *plmc_prof_name(int id) { return (id >= 0 && id < plmc::PK_COUNT) ? plmc::kProfNames[id] : ""; }

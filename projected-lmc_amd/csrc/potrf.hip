@@ -15,6 +15,7 @@
 // updated (depth 128); the large trailing update then runs once per pair with depth 256, which halves
 // the read-modify-write traffic of the trailing matrix (the HBM-bound part of the sweep).
 // Tiles of W are written (not accumulated) the first time they are touched, so W needs no memset.
+#include <stdlib.h>
 #include "api_common.hpp"
 #include "covariance.hpp"
 #include "diag_block.hpp"
@@ -210,7 +211,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     const double flopsR = 2.0 * nb * nb * nr * (depth * Taug + depthW);
     const int nfirst = with_inverse ? r_hi - r_lo + 1 : 0;                       // first-touch W columns: no read
     const double bytes = (2.0 * (tilesU + tilesA + nr * cm.nW) - nr * nfirst) * nb * nb * esz;
-    ProfScope ps(PK_TRAIL, st, q * (flopsU + flopsR), q * bytes);
+    ProfScope ps(nrows == 1 ? PK_TRAIL_ROW : PK_TRAIL, st, q * (flopsU + flopsR), q * bytes);
     hipLaunchKernelGGL(k_update<T>, dim3(cm.nU + cm.Taug + cm.nW, nrows, q), dim3(NTHREADS), 0, st, A, lda, strideA,
                        ib0, r_lo, r_hi, cm, nrows == 1 ? 1 : 0);
   };
@@ -230,35 +231,49 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       if (r + 1 < g1) update(r + 1, 1, g0, r, s);
     }
   };
-  // Look-ahead: the depth-512 update of group K is split into the block rows the next group needs
-  // ("head") and the rest ("tail"); the latency-bound chain of group K+1 runs on a helper stream
-  // concurrently with the tail.  Falls back to a single stream if the helper cannot be created.
-  hipStream_t s1 = side_stream();
-  hipEvent_t e_head = sync_event(0), e_chain = sync_event(1), e_entry = sync_event(2);
-  const bool la = s1 && e_head && e_chain && e_entry && m > 2 * GRP;
-  if (la) {
-    (void)hipEventRecord(e_entry, st);
-    (void)hipStreamWaitEvent(s1, e_entry, 0);
-  }
-  chain(0, st);
-  for (int g0 = 0; g0 < m; g0 += GRP) {
-    const int g1 = g0 + GRP < m ? g0 + GRP : m;
-    const int first = g1, nrest = m - first;
-    if (nrest <= 0) break;
-    if (!la) {
-      update(first, nrest, g0, g1 - 1, st);
-      chain(first, st);
-      continue;
+  // Look-ahead on two streams.  C (helper, high priority) carries the latency-bound work: the chain of
+  // each group and the "head" update (the GRP block rows the NEXT chain needs); T carries the "tail"
+  // update of all other rows (CU-masked so that a few CUs always have LDS / wave slots free for C).
+  //   head(g) needs chain(g) [same stream] and tail(g-1) [event, normally long complete];
+  //   tail(g) needs chain(g) [event] and tail(g-1) [same stream]; head(g) and tail(g) touch disjoint rows.
+  // C never waits on an event that is still pending when the chain is the bottleneck (few latents), and T
+  // runs its updates back to back when the updates are (many latents).  Falls back to one stream.
+  hipStream_t C = side_stream();
+  hipStream_t s2 = getenv("PLMC_NO_CUMASK") ? nullptr : tail_stream(8);
+  hipEvent_t e_chain = sync_event(0), e_tail = sync_event(1), e_entry = sync_event(2), e_done = sync_event(3);
+  const bool la = C && e_chain && e_tail && e_entry && e_done && m > 2 * GRP;
+  if (!la) {
+    chain(0, st);
+    for (int g0 = 0; g0 + GRP < m; g0 += GRP) {
+      update(g0 + GRP, m - g0 - GRP, g0, g0 + GRP - 1, st);
+      chain(g0 + GRP, st);
     }
-    const int nhead = nrest < GRP ? nrest : GRP;
-    update(first, nhead, g0, g1 - 1, st);
-    (void)hipEventRecord(e_head, st);
-    (void)hipStreamWaitEvent(s1, e_head, 0);
-    chain(first, s1);
-    (void)hipEventRecord(e_chain, s1);
-    update(first + nhead, nrest - nhead, g0, g1 - 1, st);
-    (void)hipStreamWaitEvent(st, e_chain, 0);
+    return launch_status(__func__);
   }
+  hipStream_t Tq = s2 ? s2 : st;
+  (void)hipEventRecord(e_entry, st);
+  (void)hipStreamWaitEvent(C, e_entry, 0);
+  if (Tq != st) (void)hipStreamWaitEvent(Tq, e_entry, 0);
+  chain(0, C);
+  bool tail_pending = false, any_tail = false;
+  for (int g0 = 0; g0 + GRP < m; g0 += GRP) {
+    const int g1 = g0 + GRP, first = g1, nrest = m - first;
+    const int nhead = nrest < GRP ? nrest : GRP;
+    (void)hipEventRecord(e_chain, C);                       // panels of group g0 complete
+    if (tail_pending) (void)hipStreamWaitEvent(C, e_tail, 0);
+    update(first, nhead, g0, g1 - 1, C);
+    tail_pending = nrest > nhead;
+    if (tail_pending) {
+      (void)hipStreamWaitEvent(Tq, e_chain, 0);
+      update(first + nhead, nrest - nhead, g0, g1 - 1, Tq);
+      (void)hipEventRecord(e_tail, Tq);
+      any_tail = true;
+    }
+    chain(first, C);
+  }
+  (void)hipEventRecord(e_done, C);
+  (void)hipStreamWaitEvent(st, e_done, 0);
+  if (any_tail && Tq != st) (void)hipStreamWaitEvent(st, e_tail, 0);
   return launch_status(__func__);
 }
 

@@ -50,7 +50,15 @@ _PLAIN = {
 
 
 def prof_enable(on):
-    return lib().cdll.plmc_prof_enable(1 if on else 0)
+    """on: False / True (every kernel class) or an iterable of class names (plmc_prof_name) to bracket."""
+    L = lib().cdll
+    if isinstance(on, (list, tuple, set)):
+        names = [L.plmc_prof_name(i).decode() for i in range(L.plmc_prof_kernels())]
+        mask = 0
+        for k in on:
+            mask |= 1 << names.index(k)
+        return L.plmc_prof_enable(mask << 1)
+    return L.plmc_prof_enable(1 if on else 0)
 
 
 def prof_collect():
