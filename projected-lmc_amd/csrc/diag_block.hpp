@@ -1,4 +1,4 @@
-// diag_block.hpp -- factor AND invert one NB x NB (128 x 128) diagonal block inside LDS.
+// diag_block.hpp -- factor AND invert one NB x NB (128 x 128) diagonal block.
 //
 // This is the latency-critical step of the blocked Cholesky (one workgroup per latent GP, on the
 // critical path of every block row).  The block is processed as 8 x 8 sub-blocks of 16 x 16 by
@@ -6,23 +6,20 @@
 //   (a) the 16 x 16 diagonal sub-block is factored and inverted by ONE wave entirely in registers:
 //       lane j < 16 owns column j of the sub-block, lane 16 + c owns column c of the identity part;
 //       pivots and multipliers are broadcast with v_readlane (no LDS, no barrier inside);
-//   (b) the 16-row panel right of it (and the already-started columns of the inverse) is multiplied
-//       by the 16 x 16 inverse on MFMA (v_mfma_*_16x16x4, 4 instructions per 16 x 16 tile);
-//   (c) the remaining rows are updated with rank-16 MFMA products (upper tiles of U, live tiles of W).
-// Result: U_kk (upper) and W_kk = U_kk^-T (lower), both kept packed-triangular in LDS
-// (66 KB fp32 / 132 KB fp64).  3 barriers per sub-block row, 24 in total.
+//   (b) the 7 other tiles of that sub-block row are multiplied by the 16 x 16 inverse on MFMA;
+//   (c) the rows below are updated with rank-16 MFMA products.
+// All 64 tiles that change live in the accumulator registers of 7 worker waves for the whole kernel;
+// LDS (19 KB fp32) only carries the finished sub-block row to the waves that need it as an operand.
+// Result: U_kk (upper) in place, W_kk = U_kk^-T (lower) and its transpose.  2 barriers per sub-block row.
 #pragma once
 #include "gemm_core.hpp"
 #include "covariance.hpp"
 
 namespace plmc {
 
-__device__ __forceinline__ int rowU(int i) { return i * NB - (i * (i - 1)) / 2 - i; }   // U[i][j] at rowU(i)+j, j>=i
-__device__ __forceinline__ int rowL(int i) { return (i * (i + 1)) / 2; }                // W[i][c] at rowL(i)+c, c<=i
-constexpr int TRI = NB * (NB + 1) / 2;
 constexpr int SB = 16;               // sub-block edge
 constexpr int NSB = NB / SB;         // 8
-constexpr int DIAG_NT = 1024;        // threads of the diagonal-block kernel
+constexpr int DIAG_NT = 512;         // threads of the diagonal-block kernel: 8 waves -> 256 registers each
 
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
@@ -35,205 +32,297 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
   return __builtin_bit_cast(double, r);
 }
 
-// 1/sqrt(x) on the serial pivot path: hardware v_rsq seed + Newton steps (y <- y (1.5 - 0.5 x y^2))
-// instead of the ~40-instruction IEEE sqrt + divide expansion; result is within ~1 ulp.
-__device__ __forceinline__ float rsqrt_refined(float x) {
-  float y = __builtin_amdgcn_rsqf(x);
-  return y * (1.5f - 0.5f * x * y * y);
+// Reciprocal and reciprocal square root of a pivot from the hardware units (v_rcp / v_rsq, 1 ulp in fp32)
+// instead of the ~40-instruction IEEE divide / sqrt expansions; fp64 adds Newton steps to full precision.
+__device__ __forceinline__ float pivot_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double pivot_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y * (2.0 - x * y);
+  return y * (2.0 - x * y);
 }
-__device__ __forceinline__ double rsqrt_refined(double x) {
+__device__ __forceinline__ float pivot_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double pivot_rsqrt(double x) {
   double y = __builtin_amdgcn_rsq(x);
   y = y * (1.5 - 0.5 * x * y * y);
   return y * (1.5 - 0.5 * x * y * y);
 }
 
-// One wave: factor + invert the 16 x 16 sub-block s held in LDS.  Branch-free: every lane runs the
-// same instruction stream; loads / stores that do not apply to a lane are redirected to a dummy LDS
-// slot (an exec-masked branch per element costs ~10 instructions on the serial path).  A non-positive
-// pivot turns into NaN/inf here and is detected from the stored diagonal afterwards.
+// LDS plan of k_diag (elements of T): two row buffers of 8 tiles (tile 0 = W16 of that row, tiles 1..7 the
+// other finished tiles), one tile for the factored diagonal sub-block, one all-zero tile, and the
+// hand-over buffer [16][32] = [ next diagonal tile | I ].
+constexpr int DIAG_TILE = SB * SB;
+constexpr int DIAG_ROWBUF = NSB * DIAG_TILE;
+constexpr int DIAG_SLD = 2 * SB;
+constexpr int DIAG_UBUF = 2 * DIAG_ROWBUF, DIAG_ZERO = DIAG_UBUF + DIAG_TILE, DIAG_SCR = DIAG_ZERO + DIAG_TILE;
+constexpr int DIAG_LDS = DIAG_SCR + SB * DIAG_SLD;
+constexpr int DIAG_NWK = DIAG_NT / 64 - 1;                 // 7 worker waves (wave 0 factors)
+
+// Wave 0: factor + invert the 16 x 16 sub-block handed over in `S` = [ tile | I ] (row-major 16 x 32; the
+// tile's entries below the diagonal are finite garbage and only ever meet other garbage).
+// Lane j < 16 owns column j of the sub-block, lane 16 + c column c of the identity; pivots and multipliers
+// travel by v_readlane, so there is no LDS traffic and no barrier inside.  Branch-free; a non-positive
+// pivot turns into NaN / inf and is found from the diagonal of U afterwards (k_logdet).
+// The elimination runs on UNSCALED rows (root-free LDL^T form): the serial chain per pivot is only
+// readlane -> v_rcp -> mul -> fma; the 16 rows are scaled by rsqrt(pivot) at the end, off the chain.
+//   ub <- U16 as a row-major 16 x 16 tile (entries below the diagonal are garbage)
+//   wb <- W16 = U16^-T as a row-major 16 x 16 tile (zeros above the diagonal included)
 template <typename T>
-__device__ __forceinline__ void factor16(T *sU, int s, int lane) {
-  const int o = SB * s;
-  const int col = lane & 15;
-  const bool isU = lane < 16, isW = (lane >= 16) & (lane < 32);
-  const int dummy = 2 * TRI + NB + lane;                // private scratch word of this lane
-  T x[SB];
+__device__ __forceinline__ void factor16(const T *S, T *ub, T *wb, int lane) {
+  const int l32 = lane & 31;
+  T x[SB], dk[SB];
 #pragma unroll
-  for (int i = 0; i < SB; ++i) {
-    const bool vu = isU & (i <= col);
-    const T v = sU[vu ? rowU(o + i) + o + col : dummy];
-    x[i] = vu ? v : ((isW & (i == col)) ? T(1) : T(0));
-  }
+  for (int i = 0; i < SB; ++i) x[i] = S[i * DIAG_SLD + l32];
 #pragma unroll
   for (int k = 0; k < SB; ++k) {
-    const T piv = lane_bcast(x[k], k);
-    const T inv = rsqrt_refined(piv);
-    const T rowk = x[k] * inv;
-    x[k] = rowk;
+    // all broadcasts of step k back to back into distinct SGPRs (left to itself the scheduler emits
+    // readlane / wait states / fma one pair at a time through a single SGPR), then the arithmetic
+    T m[SB];
+    dk[k] = lane_bcast(x[k], k);               // pivot d_k (wave-uniform)
 #pragma unroll
-    for (int i = k + 1; i < SB; ++i) {
-      const T m = lane_bcast(rowk, i);      // U[k][i]
-      x[i] -= m * rowk;
-    }
+    for (int i = k + 1; i < SB; ++i) m[i] = lane_bcast(x[k], i);   // unscaled U~[k][i]
+    __builtin_amdgcn_sched_barrier(0);
+    const T tk = x[k] * pivot_rcp(dk[k]);      // row k / d_k
+#pragma unroll
+    for (int i = k + 1; i < SB; ++i) x[i] -= m[i] * tk;
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int i = 0; i < SB; ++i) {
-    const bool vu = isU & (i <= col), vw = isW & (i >= col);
-    const int idx = vu ? rowU(o + i) + o + col : (vw ? TRI + rowL(o + i) + o + col : dummy);
-    sU[idx] = x[i];
+  for (int k = 0; k < SB; ++k) x[k] *= pivot_rsqrt(dk[k]);
+  if (lane < 32) {
+    T *dst = (lane < 16 ? ub : wb) + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < SB; ++i) dst[i * SB] = x[i];
   }
 }
 
-// grid (q); NT threads (DIAG_NT = 1024: 16 waves share the rank-16 updates).  Wout (may be null): where to store W_kk as a full lower block (ldw).
+// grid (q); 512 threads = wave 0 (the serial 16 x 16 factor/invert steps) + 7 worker waves.
+//
+// The block is the augmented matrix [A_kk | I] of 8 x 8 sub-blocks of 16 x 16, eliminated right-looking.
+// Sub-block row t has 8 tiles that ever change: the diagonal tile U(t,t) and 7 others (U(t,t+1..7) and
+// W(t,0..t-1); W(t,t) comes straight out of the 16 x 16 inversion).  Worker w owns ONE of the 7 others in
+// every row (accumulator slot t: tile j = 1 + (w + t) mod 7 of row t) plus one diagonal tile (slot 8:
+// t_d = w, or 7 for worker 0), all kept NEGATED in MFMA accumulators for the whole kernel, so that a
+// rank-16 update is a plain accumulate and the work of every step is spread evenly.  The worker code is
+// fully unrolled over the sub-block rows: every accumulator index is static, and a tile that is not live
+// in some step is pointed at an all-zero LDS tile instead of being branched around (a conditionally
+// updated accumulator costs register copies at every join).  Per sub-block row s:
+//   wave 0 : waits for the hand-over flag, factors/inverts tile (s,s) -> LDS                     | barrier 1
+//   workers: apply finished row s-1 to their tiles of rows >= s                                  |
+//   workers: multiply their row-s tile by W16 (the accumulator is fed back as the B operand, k permuted
+//            consistently in A), publish it in LDS; wave 0 stores the diagonal tiles             | barrier 2
+//   owner of (s+1,s+1): applies row s to it, hands it to wave 0 through LDS and raises the flag;
+//   then every worker stores its finished row-s tile to global memory (off the critical path).
+// Result: U_kk (upper) in place, Vd = W_kk^T and (optionally) W_kk: lower / diagonal tiles only -- the
+// caller zeroes the other tiles once per sweep.  log det and the pivot check are done by k_logdet.
 template <typename T, int DBG = 0, int NT = DIAG_NT>
 __global__ __launch_bounds__(NT) void k_diag(T *A, int64_t lda, int64_t strideA, int kblk, T *__restrict__ Vd,
-                                                   int64_t strideV, T *Wout, int64_t ldw, int64_t strideW,
-                                                   double *__restrict__ logdet, int *__restrict__ info) {
+                                             int64_t strideV, T *Wout, int64_t ldw, int64_t strideW) {
+  static_assert(NT == 512, "tile ownership is laid out for 8 waves");
   using Tr = Traits<T>;
-  __builtin_amdgcn_s_setprio(3);       // critical path: win issue arbitration against co-resident update tiles
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  T *sU = reinterpret_cast<T *>(smem_raw);
-  T *sW = sU + TRI;
+  using acc_t = typename Tr::acc_t;
+  __shared__ __align__(16) T smem[DIAG_LDS];
+  __shared__ int handover;             // highest sub-block row whose diagonal tile is ready in the hand-over buffer
+  T *scr = smem + DIAG_SCR;
   const int lat = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6) - 1;          // worker id, -1 = factor wave
+  const int fm = lane & 15, fk = lane >> 4, lo = fk * SB + fm;
   T *blk = A + (int64_t)lat * strideA + (int64_t)kblk * NB * lda + (int64_t)kblk * NB;
-
-  // thread owns column j = tid & 127 and rows (tid >> 7) + 2 * it; the global loads are issued in groups
-  // of 8 before their LDS stores so that their latencies overlap instead of adding up
-  {
-    constexpr int RPP = NT / 128;                        // rows covered per pass
-    const int j = tid & 127, i0 = tid >> 7;
-#pragma unroll 1
-    for (int it0 = 0; it0 < 128 / RPP; it0 += 8) {
-      T v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + RPP * (it0 + u);
-        v[u] = (j >= i) ? blk[(int64_t)i * lda + j] : T(0);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + RPP * (it0 + u);
-        if (j >= i) sU[rowU(i) + j] = v[u];
-        if (j <= i) sW[rowL(i) + j] = (i == j) ? T(1) : T(0);
-      }
-    }
-  }
-  __syncthreads();
-
-  const int fm = lane & 15, fk = lane >> 4;
-  // Schedule: wave 0 owns the critical path -- it updates the next 16 x 16 diagonal tile first and
-  // factors it right away, while waves 1..3 apply the rest of the rank-16 update; 2 barriers per step.
-  if (wave == 0 && !(DBG & 1)) factor16<T>(sU, 0, lane);
-  __syncthreads();
-  for (int s = 0; s < NSB; ++s) {
-    const int o = SB * s;
-    // ---- (b) row panel of sub-block row s: P <- W16 * P   (7 tiles: U columns right, W columns left)
-    for (int t = wave; t < ((DBG & 2) ? 0 : NSB - 1); t += NT / 64) {
-      const bool isU = t < NSB - 1 - s;
-      const int cb = isU ? s + 1 + t : t - (NSB - 1 - s);
-      typename Tr::acc_t acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = T(0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int k = ks * 4 + fk;
-        const T a = (k <= fm) ? sW[rowL(o + fm) + o + k] : T(0);
-        const T b = isU ? sU[rowU(o + k) + SB * cb + fm] : sW[rowL(o + k) + SB * cb + fm];
-        acc = Tr::mfma(a, b, acc);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = Tr::acc_row(lane, r);
-        if (isU) sU[rowU(o + row) + SB * cb + fm] = acc[r];
-        else sW[rowL(o + row) + SB * cb + fm] = acc[r];
-      }
-    }
-    __syncthreads();
-    // ---- (c) rank-16 update of the rows below: U tiles (t,u), s<t<=u ; W tiles (t,c), c<=s<t
-    // round-robin over waves 1..NW-1 with a wrapping counter (an integer modulo per candidate tile
-    // cost more than the tile itself)
-    int rr = 0;
-    auto mine = [&]() { const bool m = (rr + 1 == wave); rr = (rr + 1 == NT / 64 - 1) ? 0 : rr + 1; return m; };
-    for (int t = s + 1; t < ((DBG & 4) ? 0 : NSB); ++t) {
-      for (int u = t; u < NSB; ++u) {
-        const bool crit = (t == s + 1) && (u == t);        // next diagonal tile: wave 0
-        if (crit ? wave != 0 : !mine()) continue;
-        typename Tr::acc_t acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = Tr::acc_row(lane, r);
-          acc[r] = (t < u || fm >= row) ? sU[rowU(SB * t + row) + SB * u + fm] : T(0);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int k = ks * 4 + fk;
-          const T a = -sU[rowU(o + k) + SB * t + fm];
-          const T b = sU[rowU(o + k) + SB * u + fm];
-          acc = Tr::mfma(a, b, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = Tr::acc_row(lane, r);
-          if (t < u || fm >= row) sU[rowU(SB * t + row) + SB * u + fm] = acc[r];
-        }
-      }
-      for (int c = 0; c <= s; ++c) {
-        if (!mine()) continue;
-        typename Tr::acc_t acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = sW[rowL(SB * t + Tr::acc_row(lane, r)) + SB * c + fm];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int k = ks * 4 + fk;
-          const T a = -sU[rowU(o + k) + SB * t + fm];
-          const T b = (c < s || fm <= k) ? sW[rowL(o + k) + SB * c + fm] : T(0);
-          acc = Tr::mfma(a, b, acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sW[rowL(SB * t + Tr::acc_row(lane, r)) + SB * c + fm] = acc[r];
-      }
-    }
-    if (wave == 0 && s + 1 < NSB && !(DBG & 1)) factor16<T>(sU, s + 1, lane);
-    __syncthreads();
-  }
-
-  // ---- write back: U_kk (upper part), Vd = W_kk^T (full block, zeros below), optional W_kk (lower)
   T *vd = Vd + (int64_t)lat * strideV + (int64_t)kblk * NB * NB;
   T *wo = Wout ? Wout + (int64_t)lat * strideW : nullptr;
-  for (int e = tid; e < NB * NB; e += NT) {
-    int i = e >> 7, j = e & 127;
-    if (j >= i) {
-      blk[(int64_t)i * lda + j] = sU[rowU(i) + j];
-      vd[e] = sW[rowL(j) + i];                     // V[i][j] = W[j][i]
-    } else {
-      vd[e] = T(0);
-    }
-    if (wo) wo[(int64_t)i * ldw + j] = (j <= i) ? sW[rowL(i) + j] : T(0);
-  }
-  // log det of the block = 2 sum log(U_ii): one log per thread, fixed-order reduction; a pivot that was
-  // not positive left NaN / inf / <= 0 on the diagonal -> report the first one through info.
-  const T udiag = tid < NB ? sU[rowU(tid) + tid] : T(1);
-  const bool okp = udiag > T(0) && udiag < T(3.0e38);
-  double lg = (tid < NB && okp) ? 2.0 * log((double)udiag) : 0.0;
-  int badi = (tid < NB && !okp) ? kblk * NB + tid + 1 : 0x7fffffff;
+  const unsigned ldu = (unsigned)lda, ldwu = (unsigned)ldw;            // offsets inside the block fit 32 bits
+
+  if (w < 0) {
+    // =========================== wave 0: the serial chain ===========================
+    __builtin_amdgcn_s_setprio(3);     // above its own workers, which are above co-resident update tiles
+    {                                  // hand-over buffer for s = 0: [ A(0,0) | I ]
+      T v[4];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    lg += __shfl_down(lg, off, 64);
-    const int ob = __shfl_down(badi, off, 64);
-    badi = ob < badi ? ob : badi;
+      for (int r = 0; r < 4; ++r) v[r] = blk[(unsigned)(fk + 4 * r) * ldu + (unsigned)fm];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        scr[(fk + 4 * r) * DIAG_SLD + fm] = v[r];
+        scr[(fk + 4 * r) * DIAG_SLD + SB + fm] = (fk + 4 * r) == fm ? T(1) : T(0);
+        smem[DIAG_ZERO + lo + r * 4 * SB] = T(0);
+      }
+      if (lane == 0) handover = 0;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < NSB; ++s) {
+      const int o = SB * s;
+      int ls = lane;
+      asm volatile("" : "+v"(ls));     // keeps factor16's lane masks out of the loop-invariant registers
+      T *rb_cur = smem + (s & 1) * DIAG_ROWBUF, *ub = smem + DIAG_UBUF;
+      if (s > 0) {
+        while (__atomic_load_n(&handover, __ATOMIC_ACQUIRE) < s) __builtin_amdgcn_s_sleep(1);
+      }
+      if (!(DBG & 1)) factor16<T>(scr, ub, rb_cur, ls);
+      __syncthreads();
+      // idle until the next hand-over: store the diagonal tiles U16 (upper), W16 and V16 = W16^T
+      if (!(DBG & 1)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = fk + 4 * r, col = fm;
+          const T uv = ub[row * SB + col], wv = rb_cur[row * SB + col], wt = rb_cur[col * SB + row];
+          if (col >= row) blk[(unsigned)(o + row) * ldu + (unsigned)(o + col)] = uv;
+          vd[(o + row) * NB + o + col] = wt;
+          if (wo) wo[(unsigned)(o + row) * ldwu + (unsigned)(o + col)] = wv;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+
+  // =========================== workers ===========================
+  __builtin_amdgcn_s_setprio(2);
+  const int td = w == 0 ? NSB - 1 : w;                                  // row of this worker's diagonal tile
+  // tile j (1..7) of row t owned by this worker
+  auto tile_j = [&](int t) { const int x = w + t; return 1 + (x >= DIAG_NWK ? (x >= 2 * DIAG_NWK ? x - 2 * DIAG_NWK : x - DIAG_NWK) : x); };
+  acc_t acc[NSB + 1];
+  {
+    T ld[NSB + 1][4];
+#pragma unroll
+    for (int t = 0; t <= NSB; ++t) {
+      const int tt = t < NSB ? t : td, jj = t < NSB ? tile_j(t) : 0;
+      const bool isU = jj < NSB - tt;
+      const int u = isU ? tt + jj : 0;                                  // W tiles: any valid address, value unused
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        ld[t][r] = blk[(unsigned)(SB * tt + Tr::acc_row(lane, r)) * ldu + (unsigned)(SB * u + fm)];
+    }
+#pragma unroll
+    for (int t = 0; t <= NSB; ++t) {
+      const int tt = t < NSB ? t : td, jj = t < NSB ? tile_j(t) : 0;
+      const bool isU = jj < NSB - tt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool keep = isU && (jj > 0 || fm >= Tr::acc_row(lane, r));
+        acc[t][r] = keep ? -ld[t][r] : T(0);
+      }
+    }
   }
   __syncthreads();
-  double *red = reinterpret_cast<double *>(sU);
-  int *redb = reinterpret_cast<int *>(red + NT / 64);
-  if (lane == 0) { red[wave] = lg; redb[wave] = badi; }
+
+#pragma unroll
+  for (int s = 0; s < NSB; ++s) {
+    const int o = SB * s;
+    const int RBC = (s & 1) * DIAG_ROWBUF, RBP = ((s ^ 1) & 1) * DIAG_ROWBUF;
+    if (s > 0 && !(DBG & 4)) {
+      // ---- apply finished row sr = s - 1:  N(t, j) += U(sr, t)^T * [ U(sr, u) | W(sr, c) ]
+      const int sr = s - 1;
+      T av[NSB + 1][4], bv[NSB + 1][4];
+#pragma unroll
+      for (int t = s; t <= NSB; ++t) {
+        const int tt = t < NSB ? t : td, jj = t < NSB ? tile_j(t) : 0;
+        const bool isU = jj < NSB - tt;
+        const int uc = isU ? tt + jj : jj - (NSB - tt);
+        // the diagonal tile of row s was brought up to date at the hand-over; rows < s are finished
+        const bool live = (t < NSB || td > s) && (isU || uc <= sr);
+        const int bt = isU ? uc - sr : (uc == sr ? 0 : NSB - sr + uc);
+        const int aoff = live ? RBP + (tt - sr) * DIAG_TILE : DIAG_ZERO;
+        const int boff = live ? RBP + bt * DIAG_TILE : DIAG_ZERO;
+        const T *pa = smem + aoff + lo, *pb = smem + boff + lo;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { av[t][ks] = pa[ks * 4 * SB]; bv[t][ks] = pb[ks * 4 * SB]; }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int t = s; t <= NSB; ++t) acc[t] = Tr::mfma(av[t][ks], bv[t][ks], acc[t]);
+    }
+    __syncthreads();
+    // ---- row panel: tile <- W16 * tile = (-W16) * N, published for the rows below
+    const int pj = tile_j(s);
+    if (!(DBG & 2)) {
+      acc_t p;
+      T wv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[r] = T(0); wv[r] = -smem[RBC + fm * SB + Tr::acc_row(lane, r)]; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p = Tr::mfma(wv[r], acc[s][r], p);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) smem[RBC + pj * DIAG_TILE + Tr::acc_row(lane, r) * SB + fm] = p[r];
+      acc[s] = p;                                                      // finished: kept for the global store
+    }
+    __syncthreads();
+    // ---- hand the next diagonal tile to wave 0 (no barrier: wave 0 polls the flag, the workers move on)
+    if (s + 1 < NSB && td == s + 1) {
+      if (!(DBG & 4)) {
+        const T *pa = smem + RBC + DIAG_TILE + lo;                     // U(s, s+1) is both operands
+        T av[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) av[ks] = pa[ks * 4 * SB];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc[NSB] = Tr::mfma(av[ks], av[ks], acc[NSB]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scr[Tr::acc_row(lane, r) * DIAG_SLD + fm] = -acc[NSB][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __atomic_store_n(&handover, s + 1, __ATOMIC_RELEASE);
+    }
+    // ---- store this worker's finished tile of row s
+    if (!(DBG & 2)) {
+      const bool isU = pj < NSB - s;
+      const int uc = isU ? s + pj : pj - (NSB - s);
+      if (isU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          blk[(unsigned)(o + Tr::acc_row(lane, r)) * ldu + (unsigned)(SB * uc + fm)] = acc[s][r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vd[(SB * uc + fm) * NB + o + Tr::acc_row(lane, r)] = acc[s][r];
+        if (wo) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            wo[(unsigned)(o + Tr::acc_row(lane, r)) * ldwu + (unsigned)(SB * uc + fm)] = acc[s][r];
+        }
+      }
+    }
+  }
+}
+
+// log det = 2 sum log(U_ii) and the pivot check of a finished sweep, from the diagonal of U (a pivot that
+// was not positive left NaN / inf / <= 0 behind; info = 1 + index of the first one, 0 if none).
+// grid (q), 256 threads; fixed-order reduction.
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_logdet(const T *__restrict__ A, int64_t n_pad, int64_t lda, int64_t strideA,
+                                                      double *__restrict__ logdet, int *__restrict__ info) {
+  __shared__ double red[NTHREADS];
+  __shared__ int redb[NTHREADS];
+  const int lat = blockIdx.x, tid = threadIdx.x;
+  const T *Al = A + (int64_t)lat * strideA;
+  double lg = 0.0;
+  int bad = 0x7fffffff;
+  for (int64_t i = tid; i < n_pad; i += NTHREADS) {
+    const T d = Al[i * lda + i];
+    const bool ok = d > T(0) && d < T(3.0e38);
+    if (ok) lg += 2.0 * log((double)d);
+    else bad = (int)i + 1 < bad ? (int)i + 1 : bad;
+  }
+  red[tid] = lg;
+  redb[tid] = bad;
   __syncthreads();
-  if (tid == 0) {
-    const double lacc = red[0] + red[1];                  // pivots live in threads 0..127 = waves 0, 1
-    int bad = redb[0] < redb[1] ? redb[0] : redb[1];
-    bad = bad == 0x7fffffff ? 0 : bad;
-    if (kblk == 0) { logdet[lat] = lacc; info[lat] = bad; }
-    else { logdet[lat] += lacc; if (bad && info[lat] == 0) info[lat] = bad; }
+  for (int o = NTHREADS / 2; o > 0; o >>= 1) {
+    if (tid < o) { red[tid] += red[tid + o]; redb[tid] = redb[tid + o] < redb[tid] ? redb[tid + o] : redb[tid]; }
+    __syncthreads();
+  }
+  if (tid == 0) { logdet[lat] = red[0]; info[lat] = redb[0] == 0x7fffffff ? 0 : redb[0]; }
+}
+
+// Zero the tiles of the diagonal-block outputs that k_diag never writes: Vd tiles (a, b) with a > b and
+// W_kk tiles (b, a) above the diagonal (16 x 16 tiles of every 128 x 128 diagonal block).  grid (m, q).
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_zero_diag_out(T *__restrict__ Vd, int64_t strideV, T *Wd, int64_t ldw,
+                                                             int64_t strideW, int64_t wdiag_step) {
+  const int kb = blockIdx.x, lat = blockIdx.y;
+  T *vd = Vd + (int64_t)lat * strideV + (int64_t)kb * NB * NB;
+  T *wo = Wd ? Wd + (int64_t)lat * strideW + (int64_t)kb * wdiag_step : nullptr;
+  for (int e = threadIdx.x; e < NB * NB; e += NTHREADS) {
+    const int i = e >> 7, j = e & 127;
+    if ((i >> 4) > (j >> 4)) vd[e] = T(0);
+    if (wo && (j >> 4) > (i >> 4)) wo[(int64_t)i * ldw + j] = T(0);
   }
 }
 

@@ -173,21 +173,12 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const int Taug = (int)(naug_pad / NB);
   const int64_t strideV = (int64_t)m * NB * NB;
   const int64_t wcol0 = n_pad + naug_pad;
-  constexpr int NTD = sizeof(T) == 4 ? DIAG_NT : DIAG_NT / 2;     // fp64 would spill at 1024 threads (128 VGPRs)
-  const size_t diag_smem = (2 * TRI + NB + 64) * sizeof(T);
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[sizeof(T) == 8]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag<T, 0, NTD>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)diag_smem);
-    attr_done[sizeof(T) == 8] = true;
-  }
   const double nb = (double)NB, nb3 = nb * nb * nb, esz = sizeof(T);
 
   auto diag = [&](int r, hipStream_t st) {
     ProfScope ps(PK_DIAG, st, q * (2.0 / 3.0) * nb3, q * 3.0 * nb * nb * esz);
     T *wout = with_inverse ? A + (int64_t)r * NB * lda + wcol0 + (int64_t)r * NB : (T *)nullptr;
-    hipLaunchKernelGGL((k_diag<T, 0, NTD>), dim3(q), dim3(NTD), diag_smem, st, A, lda, strideA, r, Vd, strideV, wout, lda,
-                       strideA, logdet, info);
+    hipLaunchKernelGGL((k_diag<T>), dim3(q), dim3(DIAG_NT), 0, st, A, lda, strideA, r, Vd, strideV, wout, lda, strideA);
   };
   auto panel = [&](int r, hipStream_t st) {
     ColMap cm{r + 1, m - 1 - r, Taug, with_inverse ? r : 0, n_pad, wcol0};
@@ -220,6 +211,13 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // more than the wall time once the look-ahead runs the chain beside the trailing update)
   const double npd = (double)n_pad;
   ProfScope whole(PK_SWEEP, st, q * (with_inverse ? 2.0 : 1.0) * npd * npd * npd / 3.0, 0.0);
+  // tiles of the diagonal-block outputs that k_diag leaves alone (they are read as parts of full 128 x 128 operands)
+  hipLaunchKernelGGL(k_zero_diag_out<T>, dim3(m, q), dim3(NTHREADS), 0, st, Vd, strideV,
+                     with_inverse ? A + wcol0 : (T *)nullptr, lda, strideA, (int64_t)NB * lda + NB);
+  auto finish = [&]() {
+    hipLaunchKernelGGL(k_logdet<T>, dim3(q), dim3(NTHREADS), 0, st, (const T *)A, n_pad, lda, strideA, logdet, info);
+    return launch_status("potrf_impl");
+  };
   // One GROUP of GRP block rows: factor/invert each diagonal block, solve its row panel, and bring the
   // next row of the group up to date (rank-(128 j) update with the rows of the group done so far).
   constexpr int GRP = 4;                 // the big update then has depth GRP * 128 = 512 (8 measured slower: longer chain)
@@ -248,7 +246,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       update(g0 + GRP, m - g0 - GRP, g0, g0 + GRP - 1, st);
       chain(g0 + GRP, st);
     }
-    return launch_status(__func__);
+    return finish();
   }
   hipStream_t Tq = s2 ? s2 : st;
   (void)hipEventRecord(e_entry, st);
@@ -274,7 +272,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   (void)hipEventRecord(e_done, C);
   (void)hipStreamWaitEvent(st, e_done, 0);
   if (any_tail && Tq != st) (void)hipStreamWaitEvent(st, e_tail, 0);
-  return launch_status(__func__);
+  return finish();
 }
 
 template <typename T>
