@@ -189,7 +189,7 @@ def main():
     # would distort the very step time being measured.  The full per-kernel table comes from extra untimed
     # steps afterwards.
     prof = not args.no_prof
-    HEAVY = ("k_trail", "k_kinv_grad", "sweep_total")
+    HEAVY = ("k_trail", "k_trail_head", "k_kinv_grad", "sweep_total")
     if prof:
         _hip.prof_enable(HEAVY)
         _hip.prof_collect()
@@ -200,13 +200,21 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     stats = _hip.prof_collect() if prof else {}
-    table, table_steps = {}, 3
+    table, table_steps, iso = {}, 3, {}
     if prof:
         _hip.prof_enable(True)
         for i in range(table_steps):
             step()
         fence()
         table = _hip.prof_collect()
+        # the same kernels with the look-ahead off (one stream, nothing overlaps): per-kernel rates undiluted
+        # by concurrent launches -- reported beside the in-situ roofline, never as the step time
+        os.environ["PLMC_SERIAL"] = "1"
+        for i in range(2):
+            step()
+        fence()
+        iso = _hip.prof_collect()
+        del os.environ["PLMC_SERIAL"]
         _hip.prof_enable(False)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -236,11 +244,17 @@ def main():
                                "frac": ach / peak, "traffic": None,
                                "avg_launch_ms": s["ms"] / s["launches"], "launches": s["launches"],
                                "flops_per_launch": s["flops"] / s["launches"]}
+            if dom in iso and iso[dom]["ms"] > 0:
+                ia = iso[dom]["flops"] / (iso[dom]["ms"] * 1e-3) / 1e12
+                res["roofline"]["isolated"] = {"achieved": ia, "frac": ia / peak, "launches": iso[dom]["launches"],
+                                               "note": "same kernel, look-ahead off (PLMC_SERIAL=1, 2 untimed steps): no "
+                                                       "concurrent launches share the GPU; `achieved` above is in situ, "
+                                                       "where the chain + head run beside this kernel"}
             # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE cannot be read from inside
             # the process: they come from the committed rocprofv3 --pmc passes of this same command)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                kname = {"k_trail": "k_update<float>", "k_kinv_grad": "k_kinv_grad<float, 8>"}.get(dom, dom + "<float>")
+                kname = {"k_trail": "k_update<float, 0>", "k_trail_head": "k_update<float, 2>", "k_kinv_grad": "k_kinv_grad<float, 8>"}.get(dom, dom + "<float>")
                 if world == 1 and kname in pmc["kernels"]:
                     res["roofline"]["traffic"] = pmc["kernels"][kname]["hbm_bytes_corrected"]
                     res["roofline"]["traffic_note"] = ("bytes/launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/"

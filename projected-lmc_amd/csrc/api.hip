@@ -16,7 +16,7 @@ char *err_buf() {
 static const char *kProfNames[PK_COUNT] = {"k_assemble", "k_write_rhs", "k_assemble_cross", "k_diag",   "k_panel",
                                            "k_trail",    "k_wdiag",     "k_trtri_row",      "k_extract_col",
                                            "k_wt_matvec", "k_kinv_grad", "k_reduce_grad", "k_kernel_vjp",
-                                           "sweep_total", "k_trail_row"};
+                                           "sweep_total", "k_trail_row", "k_trail_head"};
 struct ProfRec { int id; hipEvent_t a, b; double flops, bytes; };
 static unsigned g_prof_mask = 0;          // bit i: bracket kernel class i
 static std::vector<ProfRec> g_recs;
@@ -32,7 +32,7 @@ static hipEvent_t get_event() {
 // ---- helper stream + ordering events for the look-ahead of the blocked sweep (one per device,
 // created on first use; together with the profiler record this is all the process-global state).
 static hipStream_t g_side[64] = {nullptr};
-static hipEvent_t g_sync[64][4] = {{nullptr}};
+static hipEvent_t g_sync[64][8] = {{nullptr}};
 hipStream_t side_stream() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
@@ -65,7 +65,7 @@ hipStream_t tail_stream(int reserve_cus) {
 hipEvent_t sync_event(int idx) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  hipEvent_t &e = g_sync[dev][idx & 3];
+  hipEvent_t &e = g_sync[dev][idx & 7];
   if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
   return e;
 }

@@ -32,7 +32,7 @@ inline int launch_status(const char *fn) {
 
 // kernel classes known to the optional profiler (api.hip)
 enum ProfKernel { PK_ASSEMBLE, PK_WRITE_RHS, PK_CROSS, PK_DIAG, PK_PANEL, PK_TRAIL, PK_WDIAG, PK_TRTRI, PK_EXTRACT,
-                  PK_WTMV, PK_KINV_GRAD, PK_REDUCE, PK_VJP, PK_SWEEP, PK_TRAIL_ROW, PK_COUNT };
+                  PK_WTMV, PK_KINV_GRAD, PK_REDUCE, PK_VJP, PK_SWEEP, PK_TRAIL_ROW, PK_TRAIL_HEAD, PK_COUNT };
 
 // Brackets the launches made while it is alive with two hipEvents (no-op unless its class is enabled, plmc_prof_enable).
 // flops / bytes = ALGORITHMIC work of the bracketed launch (DESIGN.md gives the formulas).
@@ -45,7 +45,7 @@ struct ProfScope {
 
 hipStream_t side_stream();          // per-device helper stream (api.hip), nullptr on failure
 hipStream_t tail_stream(int reserve_cus);   // per-device stream with the first CUs masked out, or nullptr
-hipEvent_t sync_event(int idx);     // per-device ordering events, idx in [0,4)
+hipEvent_t sync_event(int idx);     // per-device ordering events, idx in [0,8)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -16,6 +16,7 @@
 // the read-modify-write traffic of the trailing matrix (the HBM-bound part of the sweep).
 // Tiles of W are written (not accumulated) the first time they are touched, so W needs no memset.
 #include <stdlib.h>
+#include <vector>
 #include "api_common.hpp"
 #include "covariance.hpp"
 #include "diag_block.hpp"
@@ -49,17 +50,23 @@ __global__ __launch_bounds__(NTHREADS) void k_panel(T *A, int64_t lda, int64_t s
   tile_store<T>(acc, P, lda);
 }
 
-// Rank-(128|256) update of block rows [ib0, ib0 + gridDim.y) with the panel rows of block rows
+// Rank-(128 g) update of block rows [ib0, ib0 + nrows) with the panel rows of block rows
 // r_lo..r_hi:  C[i][j] -= sum_{k in panel} P[k][i] P[k][j].   grid (nU + Taug + nW, nrows, q).
 //   U columns : tiles with jb >= ib (upper), read-modify-write.
 //   aug       : read-modify-write.
 //   W column cb < r_lo : read-modify-write, full panel depth;
 //            cb == r_lo : first touch -> plain store, full depth;
 //            cb == r_hi (> r_lo): first touch, only the rows of block r_hi contribute (W[r_lo][r_hi] = 0).
-template <typename T>
+// ROLE 0 = the big trailing ("tail") update, 1 = the single-row launches inside a group (latency-critical:
+// raised wave priority), 2 = the "head" rows the next group needs.  Separate symbols keep the three launch
+// shapes apart in kernel traces and counter passes.
+template <typename T, int ROLE>
 __global__ __launch_bounds__(NTHREADS) void k_update(T *A, int64_t lda, int64_t strideA, int ib0, int r_lo, int r_hi,
-                                                      ColMap cm, int prio) {
-  if (prio) __builtin_amdgcn_s_setprio(3);
+                                                      ColMap cm) {
+  if (ROLE == 1) __builtin_amdgcn_s_setprio(3);
+  // plain row-major tile order: an XCD-dealt super-block order (as k_kinv_grad uses) was 3 % faster for a
+  // launch that has the GPU to itself and 25 % slower in the sweep, where launches from three streams
+  // interleave and "workgroup w lands on XCD w % 8" no longer holds
   const int bx = blockIdx.x, ib = ib0 + blockIdx.y, lat = blockIdx.z;
   int64_t col0;
   int kr0 = r_lo * NB, depth = (r_hi - r_lo + 1) * NB;
@@ -188,7 +195,9 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     ProfScope ps(PK_PANEL, st, q * (double)nt * nb3, q * 2.0 * nt * nb * nb * esz);
     hipLaunchKernelGGL(k_panel<T>, dim3(nt, q), dim3(NTHREADS), 0, st, A, lda, strideA, r, cm, Vd, strideV);
   };
-  auto update = [&](int ib0, int nrows, int r_lo, int r_hi, hipStream_t st) {
+  // cls: profiler class of the launch -- PK_TRAIL (the big trailing update), PK_TRAIL_HEAD (the rows the next
+  // group needs, on the chain stream), PK_TRAIL_ROW (single row inside a group)
+  auto update = [&](int ib0, int nrows, int r_lo, int r_hi, hipStream_t st, int cls) {
     if (nrows <= 0) return;
     ColMap cm{ib0, m - ib0, Taug, with_inverse ? r_hi + 1 : 0, n_pad, wcol0};
     const double depth = (r_hi - r_lo + 1) * nb;
@@ -202,9 +211,11 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     const double flopsR = 2.0 * nb * nb * nr * (depth * Taug + depthW);
     const int nfirst = with_inverse ? r_hi - r_lo + 1 : 0;                       // first-touch W columns: no read
     const double bytes = (2.0 * (tilesU + tilesA + nr * cm.nW) - nr * nfirst) * nb * nb * esz;
-    ProfScope ps(nrows == 1 ? PK_TRAIL_ROW : PK_TRAIL, st, q * (flopsU + flopsR), q * bytes);
-    hipLaunchKernelGGL(k_update<T>, dim3(cm.nU + cm.Taug + cm.nW, nrows, q), dim3(NTHREADS), 0, st, A, lda, strideA,
-                       ib0, r_lo, r_hi, cm, nrows == 1 ? 1 : 0);
+    ProfScope ps(cls, st, q * (flopsU + flopsR), q * bytes);
+    const dim3 grid(cm.nU + cm.Taug + cm.nW, nrows, q);
+    if (cls == PK_TRAIL_ROW) hipLaunchKernelGGL((k_update<T, 1>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
+    else if (cls == PK_TRAIL_HEAD) hipLaunchKernelGGL((k_update<T, 2>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
+    else hipLaunchKernelGGL((k_update<T, 0>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
   };
 
   // whole-sweep bracket on the caller's stream (the per-kernel records of overlapped kernels add up to
@@ -218,19 +229,51 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     hipLaunchKernelGGL(k_logdet<T>, dim3(q), dim3(NTHREADS), 0, st, (const T *)A, n_pad, lda, strideA, logdet, info);
     return launch_status("potrf_impl");
   };
-  // One GROUP of GRP block rows: factor/invert each diagonal block, solve its row panel, and bring the
-  // next row of the group up to date (rank-(128 j) update with the rows of the group done so far).
-  constexpr int GRP = 4;                 // the big update then has depth GRP * 128 = 512 (8 measured slower: longer chain)
-  auto chain = [&](int g0, hipStream_t s) {
-    const int g1 = g0 + GRP < m ? g0 + GRP : m;
+  // Block rows are processed in GROUPS: within a group each diagonal block is factored/inverted, its row
+  // panel solved, and the next row of the group brought up to date (rank-(128 j) update with the rows of
+  // the group done so far); the rest of the matrix then gets ONE update of depth 128 * (group size).
+  // Deeper updates = less read-modify-write traffic on the trailing matrix, but the within-group work runs
+  // one block row at a time.  Measured on MI355X the schedule matters little (27.7 .. 28.3 ms for the sweep
+  // of the benchmark shape over a dozen schedules); large groups, smaller ones at the end, is the default.
+  std::vector<int> gb;                                    // group boundaries: gb[i] .. gb[i+1]
+  {
+    const char *genv = getenv("PLMC_GRP");                // dev knob: fixed group size
+    const int fixed = genv ? atoi(genv) : 0;
+    const int big = fixed > 0 ? fixed : ((q >= 8 && m >= 32) ? 8 : 4);
+    int r = 0;
+    gb.push_back(0);
+    const char *senv = getenv("PLMC_GRP_SCHED");          // dev knob: explicit comma-separated group sizes
+    if (senv) {
+      const char *p = senv;
+      while (*p && r < m) {
+        int g = atoi(p);
+        if (g <= 0) break;
+        if (r + g > m) g = m - r;
+        r += g;
+        gb.push_back(r);
+        while (*p && *p != ',') ++p;
+        if (*p == ',') ++p;
+      }
+    }
+    while (r < m) {
+      int g = big;
+      if (fixed <= 0 && big > 4 && m - r <= 16) g = 4;    // ramp down: the chain is the bottleneck at the end
+      if (r + g > m) g = m - r;
+      r += g;
+      gb.push_back(r);
+    }
+  }
+  const int ng = (int)gb.size() - 1;
+  auto chain = [&](int gi, hipStream_t s) {
+    const int g0 = gb[gi], g1 = gb[gi + 1];
     for (int r = g0; r < g1; ++r) {
       diag(r, s);
       panel(r, s);
-      if (r + 1 < g1) update(r + 1, 1, g0, r, s);
+      if (r + 1 < g1) update(r + 1, 1, g0, r, s, PK_TRAIL_ROW);
     }
   };
   // Look-ahead on two streams.  C (helper, high priority) carries the latency-bound work: the chain of
-  // each group and the "head" update (the GRP block rows the NEXT chain needs); T carries the "tail"
+  // each group and the "head" update (the block rows the NEXT chain needs); T carries the "tail"
   // update of all other rows (CU-masked so that a few CUs always have LDS / wave slots free for C).
   //   head(g) needs chain(g) [same stream] and tail(g-1) [event, normally long complete];
   //   tail(g) needs chain(g) [event] and tail(g-1) [same stream]; head(g) and tail(g) touch disjoint rows.
@@ -239,12 +282,12 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   hipStream_t C = side_stream();
   hipStream_t s2 = getenv("PLMC_NO_CUMASK") ? nullptr : tail_stream(8);
   hipEvent_t e_chain = sync_event(0), e_tail = sync_event(1), e_entry = sync_event(2), e_done = sync_event(3);
-  const bool la = C && e_chain && e_tail && e_entry && e_done && m > 2 * GRP;
+  const bool la = C && e_chain && e_tail && e_entry && e_done && ng > 2 && !getenv("PLMC_SERIAL");   // dev knob: one stream
   if (!la) {
     chain(0, st);
-    for (int g0 = 0; g0 + GRP < m; g0 += GRP) {
-      update(g0 + GRP, m - g0 - GRP, g0, g0 + GRP - 1, st);
-      chain(g0 + GRP, st);
+    for (int gi = 0; gi + 1 < ng; ++gi) {
+      update(gb[gi + 1], m - gb[gi + 1], gb[gi], gb[gi + 1] - 1, st, PK_TRAIL);
+      chain(gi + 1, st);
     }
     return finish();
   }
@@ -254,20 +297,20 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   if (Tq != st) (void)hipStreamWaitEvent(Tq, e_entry, 0);
   chain(0, C);
   bool tail_pending = false, any_tail = false;
-  for (int g0 = 0; g0 + GRP < m; g0 += GRP) {
-    const int g1 = g0 + GRP, first = g1, nrest = m - first;
-    const int nhead = nrest < GRP ? nrest : GRP;
-    (void)hipEventRecord(e_chain, C);                       // panels of group g0 complete
+  for (int gi = 0; gi + 1 < ng; ++gi) {
+    const int g0 = gb[gi], g1 = gb[gi + 1], first = g1, nrest = m - first;
+    const int nhead = gb[gi + 2] - gb[gi + 1];              // rows of the next group
+    (void)hipEventRecord(e_chain, C);                       // panels of group gi complete
     if (tail_pending) (void)hipStreamWaitEvent(C, e_tail, 0);
-    update(first, nhead, g0, g1 - 1, C);
+    update(first, nhead, g0, g1 - 1, C, PK_TRAIL_HEAD);
     tail_pending = nrest > nhead;
     if (tail_pending) {
       (void)hipStreamWaitEvent(Tq, e_chain, 0);
-      update(first + nhead, nrest - nhead, g0, g1 - 1, Tq);
+      update(first + nhead, nrest - nhead, g0, g1 - 1, Tq, PK_TRAIL);
       (void)hipEventRecord(e_tail, Tq);
       any_tail = true;
     }
-    chain(first, C);
+    chain(gi + 1, C);
   }
   (void)hipEventRecord(e_done, C);
   (void)hipStreamWaitEvent(st, e_done, 0);
