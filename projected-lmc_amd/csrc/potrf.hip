@@ -11,9 +11,10 @@
 // all fall out of one sweep built from two MFMA tile kernels:
 //     k_panel  : row panel  P <- V_rr^T P                      (in place, K = 128)
 //     k_update : C[i][j]  -= sum_k P[k][i] P[k][j]              (upper tiles of U, aug, live tiles of W)
-// Block rows are processed in PAIRS (two-level blocking): after block row r0 only block row r1 is
-// updated (depth 128); the large trailing update then runs once per pair with depth 256, which halves
-// the read-modify-write traffic of the trailing matrix (the HBM-bound part of the sweep).
+// Block rows are processed in GROUPS of g (two-level blocking): inside a group each row is brought up to
+// date with the rows of the group done so far (depth <= 128 (g - 1)); the large trailing update then runs
+// once per group with depth 128 g, which divides the read-modify-write traffic of the trailing matrix by
+// g.  The latency-bound chain of the next group runs beside that update on a helper stream (potrf_impl).
 // Tiles of W are written (not accumulated) the first time they are touched, so W needs no memset.
 #include <stdlib.h>
 #include <vector>
