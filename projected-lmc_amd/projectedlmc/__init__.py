@@ -6,7 +6,8 @@ C ABI in include/plmc.h).  gpytorch is not a dependency: the few of its types th
 users touch (kernels, means, likelihoods, distributions, mlls, settings, constraints) are
 provided here as thin modules with the same names and parameter layout.
 """
-from . import settings, constraints, kernels, means, likelihoods, distributions, mlls, parallel  # noqa: F401
+from . import settings, constraints, kernels, means, likelihoods, distributions, mlls, parallel, priors  # noqa: F401
+from .priors import NormalPrior, MultivariateNormalPrior  # noqa: F401
 from .kernels import RBFKernel, MaternKernel, ScaleKernel, MultitaskKernel, LCMKernel, IndexKernel  # noqa: F401
 from .means import ZeroMean, ConstantMean, MultitaskMean  # noqa: F401
 from .likelihoods import GaussianLikelihood, MultitaskGaussianLikelihood  # noqa: F401

@@ -17,40 +17,52 @@ from .likelihoods import GaussianLikelihood
 def handle_covar_(kernel, dim, decomp=None, n_funcs=1, prior_scales=None, prior_width=None, outputscales=True,
                   ker_kwargs=None):
     """Kernel factory with the reference's semantics (projected_lmc.py:107-181): an ARD kernel with
-    batch_shape=[n_funcs]; wrapped in a ScaleKernel when `outputscales`.  Lengthscales start at the
-    prior mean when `prior_scales` is given (:169-179).  `decomp` with several groups builds the
-    additive kernel of additive.py (single-output models).  The lengthscale priors themselves are
-    not added to the loss (no BASELINE config registers any)."""
+    batch_shape=[n_funcs]; wrapped in a ScaleKernel when `outputscales`.  With `prior_scales` the
+    lengthscales get a Normal (one variable) / MultivariateNormal (ARD group) prior -- mean
+    prior_scales, deviation resp. covariance diagonal prior_scales * prior_width, exactly as :140-149
+    writes them -- and start at the prior mean (:169-179).  `decomp` with several groups builds the
+    additive kernel of additive.py (single-output models)."""
+    from . import priors as _p
     ker_kwargs = {} if ker_kwargs is None else ker_kwargs
     if decomp is None:
         decomp = [list(range(dim))]
-    if prior_scales is not None and prior_width is None:
-        raise ValueError('A prior width should be provided if a prior mean is')
+    l_priors = [None] * len(decomp)
+    if prior_scales is not None:
+        if prior_width is None:
+            raise ValueError('A prior width should be provided if a prior mean is')
+        if type(prior_scales) is not list:      # one length per variable, or a list with one array per kernel
+            prior_scales = [torch.as_tensor(prior_scales)[idx_list] for idx_list in decomp]
+        if type(prior_width) is not list:
+            prior_width = [torch.as_tensor(prior_width)[idx_list] for idx_list in decomp]
+        for i_ker, idx_list in enumerate(decomp):
+            sc, wd = torch.as_tensor(prior_scales[i_ker]), torch.as_tensor(prior_width[i_ker])
+            if len(idx_list) > 1:
+                l_priors[i_ker] = _p.MultivariateNormalPrior(loc=sc, covariance_matrix=torch.diag_embed(sc * wd))
+            else:
+                l_priors[i_ker] = _p.NormalPrior(loc=sc, scale=sc * wd)
+
+    def init_from_prior(ker, prior):
+        if prior is not None and ker.has_lengthscale:
+            try:
+                ker.lengthscale = prior.mean
+            except Exception:
+                raise ValueError('Provided prior scales were of the wrong shape')
+
     if len(decomp) > 1:
         # k(x) = sum_g s_g k_g(x[idx_g]): every sub-kernel gets an output scale (:159-162)
         from .additive import AdditiveKernel
         subs = []
         for i_ker, idx_g in enumerate(decomp):
-            kg = kernel(ard_num_dims=len(idx_g), active_dims=idx_g, lengthscale_prior=None,
+            kg = kernel(ard_num_dims=len(idx_g), active_dims=idx_g, lengthscale_prior=l_priors[i_ker],
                         batch_shape=torch.Size([n_funcs]), **ker_kwargs)
-            if prior_scales is not None and kg.has_lengthscale:
-                try:
-                    sc = prior_scales[i_ker] if isinstance(prior_scales, list) else torch.as_tensor(prior_scales)[idx_g]
-                    kg.lengthscale = sc
-                except Exception:
-                    raise ValueError('Provided prior scales were of the wrong shape')
+            init_from_prior(kg, l_priors[i_ker])
             subs.append(_k.ScaleKernel(kg, batch_shape=torch.Size([n_funcs])))
         return AdditiveKernel(*subs)
     idx = decomp[0]
-    ker = kernel(ard_num_dims=len(idx), active_dims=idx, lengthscale_prior=None,
+    ker = kernel(ard_num_dims=len(idx), active_dims=idx, lengthscale_prior=l_priors[0],
                  batch_shape=torch.Size([n_funcs]), **ker_kwargs)
     covar_module = _k.ScaleKernel(ker, batch_shape=torch.Size([n_funcs])) if outputscales else ker
-    if prior_scales is not None and ker.has_lengthscale:
-        try:
-            scales = prior_scales[0] if isinstance(prior_scales, list) else torch.as_tensor(prior_scales)[idx]
-            ker.lengthscale = scales
-        except Exception:
-            raise ValueError('Provided prior scales were of the wrong shape')
+    init_from_prior(ker, l_priors[0])
     return covar_module
 
 
@@ -269,6 +281,13 @@ class ExactGPModel(ExactGP):
         if self.train_targets.dim() == 1:
             return s2[0], r[0]
         return s2.T, r.T
+
+    def kernel_cond(self):
+        """2-norm condition number of the noisy train covariance K + sigma^2 I (projected_lmc.py:367-369); a
+        diagnostic: the matrix is materialised and handed to torch.linalg.cond."""
+        tx = self.train_inputs[0]
+        lazy = self.likelihood(self.forward(tx)).lazy_covariance_matrix
+        return torch.linalg.cond(lazy.to_dense())
 
     # -- inspection helpers (projected_lmc.py:324-365)
     def _base(self):

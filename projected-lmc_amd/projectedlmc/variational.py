@@ -201,7 +201,8 @@ class VariationalMultitaskGPModel(torch.nn.Module):
 
 
 class VariationalELBO(torch.nn.Module):
-    """ELBO = (1/n) sum_points E_q[log p(y|f)] - beta * KL / num_data  [gpytorch-knowledge]."""
+    """ELBO = (1/n) sum_points E_q[log p(y|f)] - beta * KL / num_data + sum(log priors) / num_data
+    [gpytorch-knowledge: _ApproximateMarginalLogLikelihood.forward, v1.11]."""
 
     def __init__(self, likelihood, model, num_data, beta=1.0, combine_terms=True):
         super().__init__()
@@ -211,4 +212,6 @@ class VariationalELBO(torch.nn.Module):
         num_batch = variational_dist_f.event_shape[0]
         log_likelihood = self.likelihood.expected_log_prob(target, variational_dist_f, **kwargs).sum(-1) / num_batch
         kl = self.model.variational_strategy.kl_divergence() / (self.num_data / self.beta)
-        return log_likelihood - kl
+        from .priors import named_priors
+        log_prior = sum((pr.log_prob(v).sum() for _, _, pr, v in named_priors(self.model)), torch.zeros_like(kl)) / self.num_data
+        return log_likelihood - kl + log_prior

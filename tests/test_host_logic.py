@@ -144,3 +144,26 @@ def test_c_abi_exports_every_declared_symbol(repo_root):
     assert lib.plmc_block() == 128 and lib.plmc_version() >= 1
     lib.plmc_pad.restype, lib.plmc_pad.argtypes = ctypes.c_int64, [ctypes.c_int64]
     assert lib.plmc_pad(1) == 128 and lib.plmc_pad(128) == 128 and lib.plmc_pad(8193) == 8320
+
+
+def test_lengthscale_priors_match_torch_distributions():
+    """NormalPrior / MultivariateNormalPrior (projected_lmc.py:140-149) against torch.distributions; the kernel
+    factory starts the lengthscales at the prior mean and registers one prior per sub-kernel."""
+    import projectedlmc as plmc
+    from projectedlmc.priors import named_priors
+    from oracle import priors as opr
+    ps = torch.tensor([0.5, 0.7, 0.9], dtype=torch.float64)
+    pw = torch.tensor([0.2, 0.3, 0.4], dtype=torch.float64)
+    k = plmc.handle_covar_(plmc.RBFKernel, 3, n_funcs=2, prior_scales=ps, prior_width=pw, outputscales=True).double()
+    assert torch.allclose(k.base_kernel.lengthscale.detach()[0, 0], ps)
+    (entry,) = named_priors(k)
+    lp = entry[2].log_prob(entry[3])
+    ref = torch.distributions.MultivariateNormal(ps, covariance_matrix=torch.diag(ps * pw)).log_prob(entry[3])
+    assert lp.shape == (2, 1) and torch.allclose(lp, ref)
+    assert torch.allclose(lp.sum(), opr.lengthscale_log_prior(entry[3], ps, pw))
+    k2 = plmc.handle_covar_(plmc.RBFKernel, 2, decomp=[[0], [1]], prior_scales=ps[:2], prior_width=pw[:2]).double()
+    pri = named_priors(k2)
+    assert len(pri) == 2
+    for i, (_, _, pr, val) in enumerate(pri):
+        ref = torch.distributions.Normal(ps[i], ps[i] * pw[i]).log_prob(val)
+        assert torch.allclose(pr.log_prob(val), ref)
