@@ -115,3 +115,43 @@ def test_full_size_properties_fp32(eng):
     assert bool((quad > 0).all())
     lp_half = eng.exact_latent_log_prob("matern52", X, ell, osc, noise, 0.5 * y)
     assert torch.allclose(lp_half - lp.detach(), 0.5 * quad * (1 - 0.25), rtol=1e-3)
+
+
+def test_metric_shape_properties_fp32(eng):
+    """The BASELINE.json metric shape itself (n = 8192, d = 8, q = 8 latents, Matern-5/2, fp32), where the dense
+    fp64 oracle is out of reach of a test: identities that tie the separately computed outputs together.
+      (1) solve round trip: Khat alpha = y with alpha = -dlogp/dy, Khat rebuilt by the cross-assembly kernel;
+      (2) scaling (Euler) identity of the gradient kernel: os dlogp/dos + s2 dlogp/ds2 = (quad - n) / 2;
+      (3) trace link between the LOO path and the gradient path: dlogp/ds2 = (alpha.alpha - tr Khat^-1) / 2 with
+          tr Khat^-1 = sum_i 1 / sigma2_loo_i;
+      (4) permutation invariance of the log-density."""
+    n, d, q = 8192, 8, 8
+    g = torch.Generator().manual_seed(3)
+    X = (2 * torch.rand(n, d, generator=g) - 1).to(DEV)
+    y = torch.randn(q, n, generator=g).to(DEV)
+    ell = torch.linspace(0.5, 1.2, q)[:, None].expand(q, d).contiguous().to(DEV)
+    noise = torch.linspace(0.2, 0.9, q).to(DEV)
+    osc = torch.linspace(0.8, 1.5, q).to(DEV)
+    yg, ng, og = y.clone().requires_grad_(), noise.clone().requires_grad_(), osc.clone().requires_grad_()
+    lp = eng.exact_latent_log_prob("matern52", X, ell, og, ng, yg)
+    lp.sum().backward()
+    alpha = -yg.grad
+    quad = (alpha * y).sum(-1)
+    assert bool((quad > 0).all())
+    # (1) residual of Khat alpha = y, latent by latent (one 8192 x 8192 fp32 matrix at a time)
+    for i in range(q):
+        K = eng.dense_cross("matern52", X, X, ell[i:i + 1], osc[i:i + 1])[0]
+        r = K @ alpha[i] + noise[i] * alpha[i] - y[i]
+        assert float(r.norm() / y[i].norm()) < 2e-4, i
+        del K
+    # (2) Euler identity
+    lhs = osc * og.grad + noise * ng.grad
+    assert torch.allclose(lhs, 0.5 * (quad - n), rtol=2e-4, atol=1e-2)
+    # (3) trace link with the LOO outputs
+    s2, _ = eng.exact_loo("matern52", X, ell, osc, noise, y)
+    tr_kinv = (1.0 / s2.double()).sum(-1)
+    assert torch.allclose(ng.grad.double(), 0.5 * ((alpha.double() ** 2).sum(-1) - tr_kinv), rtol=2e-4, atol=1e-2)
+    # (4) permutation invariance
+    perm = torch.randperm(n, generator=g).to(DEV)
+    lp_perm = eng.exact_latent_log_prob("matern52", X[perm], ell, osc, noise, y[:, perm])
+    assert torch.allclose(lp.detach(), lp_perm, rtol=2e-5)
