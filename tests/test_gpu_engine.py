@@ -51,6 +51,27 @@ def test_logprob_and_grad_fp64(eng, kind, n, d, q, use_os):
         assert torch.allclose(os_d.grad.cpu(), w * ref[3], rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("n,d,q,env", [(1300, 3, 2, None), (2100, 4, 8, None), (1300, 3, 2, "PLMC_SERIAL"), (1300, 3, 2, "PLMC_NO_CUMASK")])
+def test_multi_group_sweep_fp64(eng, n, d, q, env, monkeypatch):
+    """Sizes at which the sweep runs its look-ahead schedule (more than two groups of block rows, head / tail
+    updates on separate streams, group sizes 4 and 8 + ramp-down), against the dense fp64 oracle; also with the
+    look-ahead and the CU mask switched off (the dev knobs must not change results)."""
+    if env:
+        monkeypatch.setenv(env, "1")
+    X, y, ell, noise, osc = _problem(n, d, q, seed=n)
+    ref = gm.exact_latent_log_prob_analytic("matern", X, ell, noise, y, osc, 2.5)
+    dev = torch.device("cuda:0")
+    ell_d, nz_d = ell.to(dev).requires_grad_(), noise.to(dev).requires_grad_()
+    y_d, os_d = y.to(dev).requires_grad_(), osc.to(dev).requires_grad_()
+    lp = eng.exact_latent_log_prob("matern52", X.to(dev), ell_d, os_d, nz_d, y_d)
+    lp.sum().backward()
+    assert torch.allclose(lp.detach().cpu(), ref[0], rtol=1e-10, atol=0)
+    assert torch.allclose(ell_d.grad.cpu(), ref[1], rtol=1e-7, atol=1e-9)
+    assert torch.allclose(nz_d.grad.cpu(), ref[2], rtol=1e-7, atol=1e-9)
+    assert torch.allclose(os_d.grad.cpu(), ref[3], rtol=1e-7, atol=1e-9)
+    assert torch.allclose(y_d.grad.cpu(), ref[4], rtol=1e-7, atol=1e-9)
+
+
 @pytest.mark.parametrize("kind", ["rbf", "matern52"])
 def test_logprob_and_grad_fp32(eng, kind):
     """fp32 tolerance: log-prob within 1e-4 relative of the fp64 oracle (BASELINE.json target),

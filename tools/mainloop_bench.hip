@@ -351,6 +351,92 @@ template <int SKIP = 0> void run_big2(const char *name, const float *A, const fl
          (double)(ck[2] - ck[0]) / ((double)(ck[3] - ck[1]) * 10.0), (double)(ck[2] - ck[0]) / ((double)K / 4 * 64));
 }
 
+// ---- candidate: 256 x 256 macro tile, 8 waves (4 x 2) of 64 x 128 = 4 x 8 MFMA tiles, two waves per SIMD
+template <int BKB>
+__global__ __launch_bounds__(512, 1) void k_big8(const float *A, const float *B, float *C, int M, int N, int K) {
+  extern __shared__ __align__(16) float smem[];
+  using vec_t = f32x4;
+  constexpr int CPR = 64;
+  constexpr int NCH = BKB * CPR / 512;                     // chunks per thread per operand per slab (2 for BK 16)
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int64_t lda = M, ldb = N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  float *sA = smem, *sB = smem + 2 * BKB * BLD;
+  vec_t ra[NCH], rb[NCH];
+  const int nkt = K / BKB;
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int row0 = tid / CPR, col0 = (tid % CPR) * 4;      // rows row0 + 8 h
+  const float *ga = A + bi * 256 + (int64_t)row0 * lda + col0, *gb = B + bj * 256 + (int64_t)row0 * ldb + col0;
+  const int64_t stepA = (int64_t)BKB * lda, stepB = (int64_t)BKB * ldb, rsA = 8 * lda, rsB = 8 * ldb;
+  auto gload = [&]() {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      ra[h] = *reinterpret_cast<const vec_t *>(ga + h * rsA);
+      rb[h] = *reinterpret_cast<const vec_t *>(gb + h * rsB);
+    }
+    ga += stepA; gb += stepB;
+  };
+  const int soff = row0 * BLD + col0;
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      *reinterpret_cast<vec_t *>(sA + buf * BKB * BLD + soff + h * 8 * BLD) = ra[h];
+      *reinterpret_cast<vec_t *>(sB + buf * BKB * BLD + soff + h * 8 * BLD) = rb[h];
+    }
+  };
+  gload(); sstore(0); __syncthreads();
+  const bool stamp = blockIdx.x == 3 && blockIdx.y == 5 && tid == 0;
+  if (stamp) { g_clk[0] = (long long)__builtin_readcyclecounter(); g_clk[1] = (long long)wall_clock64(); }
+  const int fk = lane >> 4, fm = lane & 15;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) gload();
+    const float *pa = sA + buf * BKB * BLD + wm * 64 + fm, *pb = sB + buf * BKB * BLD + wn * 128 + fm;
+#pragma unroll
+    for (int ks = 0; ks < BKB / 4; ++ks) {
+      float a[4], b[8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = pa[(ks * 4 + fk) * BLD + t * 16];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) b[t] = pb[(ks * 4 + fk) * BLD + t * 16];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  if (stamp) { g_clk[2] = (long long)__builtin_readcyclecounter(); g_clk[3] = (long long)wall_clock64(); }
+  float *Cg = C + (int64_t)bi * 256 * N + bj * 256;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Cg[(int64_t)(wm * 64 + mt * 16 + fk * 4 + r) * N + wn * 128 + nt * 16 + fm] = acc[mt][nt][r];
+}
+template <int BKB> void run_big8(const char *name, const float *A, const float *B, float *C, int M, int N, int K) {
+  const size_t sm = (size_t)2 * 2 * BKB * BLD * 4;
+  CK(hipFuncSetAttribute((const void *)(k_big8<BKB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+  dim3 g(N / 256, M / 256);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_big8<BKB>), g, dim3(512), sm, 0, A, B, C, M, N, K);
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0));
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k_big8<BKB>), g, dim3(512), sm, 0, A, B, C, M, N, K);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms, h; CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipMemcpy(&h, C + 12345, 4, hipMemcpyDeviceToHost));
+  long long ck[4]; CK(hipMemcpyFromSymbol(ck, HIP_SYMBOL(g_clk), 32));
+  printf("%-28s M=N=%d K=%5d: %7.1f TFLOP/s  (C[12345]=%.4f)  in-kernel clock %.2f GHz, %.1f clk per MFMA (wave 0)\n", name, M, K, 2.0 * M * N * K / (ms / 5 * 1e-3) / 1e12, h,
+         (double)(ck[2] - ck[0]) / ((double)(ck[3] - ck[1]) * 10.0), (double)(ck[2] - ck[0]) / ((double)K / 4 * 32));
+}
+
 template <int VAR>
 __global__ __launch_bounds__(256) void k_gemm(const float *A, const float *B, float *C, int M, int N, int K) {
   __shared__ __align__(16) float smem[tile_smem_elems<float>()];
@@ -401,7 +487,7 @@ int main() {
       printf("%-28s M=N=%d K=%5d: %7.1f TFLOP/s  (C[12345]=%.4f)\n", "mfma 32x32x2", M, K, 2.0 * M * N * K / (ms / 5 * 1e-3) / 1e12, h);
     }
   }
-  for (int K : {8192, 1024}) { run_big2<0>("big2 permuted b128", A, B, C, M, N, K); run_big2<1>("big2 no global", A, B, C, M, N, K); run_big<16>("big 256x256 BK16", A, B, C, M, N, K); run_big<32>("big 256x256 BK32", A, B, C, M, N, K);
+  for (int K : {8192, 1024}) { run_big8<16>("big8 (8 waves) BK16", A, B, C, M, N, K); run_big8<32>("big8 (8 waves) BK32", A, B, C, M, N, K); run_big2<0>("big2 permuted b128", A, B, C, M, N, K); run_big2<1>("big2 no global", A, B, C, M, N, K); run_big<16>("big 256x256 BK16", A, B, C, M, N, K); run_big<32>("big 256x256 BK32", A, B, C, M, N, K);
     run_big<16, 1>("big BK16 no global/sstore", A, B, C, M, N, K); run_big<16, 9>("  + 1 read : 4 mfma pinned", A, B, C, M, N, K); run_big<16, 17>("  + 8 mfma : 2 reads pinned", A, B, C, M, N, K); run_big<16, 8>("full + 1 read : 4 mfma", A, B, C, M, N, K); run_big<16, 2>("big BK16 no fragment loads", A, B, C, M, N, K);
     run_big<16, 3>("big BK16 no global, no frag", A, B, C, M, N, K); run_big<16, 7>("big BK16 bare + no barrier", A, B, C, M, N, K); run_big<16, 4>("big BK16 no barrier only", A, B, C, M, N, K); }
   for (int K : {8192, 1024}) {
