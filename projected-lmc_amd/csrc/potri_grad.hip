@@ -138,24 +138,33 @@ __global__ __launch_bounds__(NTHREADS) void k_kinv_grad(int kind, const T *__res
 }
 
 // grad[lat][k] = 1/2 * sum over upper tiles of partials, with the 1/ell_k factor for lengthscales.
-// grid (q); fixed summation order.
+// grid (q), 1024 threads = 30 groups of GP = 34 slots; every group walks its tiles with 4 independent
+// accumulators (the loads are latency-bound); fixed summation order throughout.
+constexpr int RED_NT = 1024;
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_reduce_grad(const double *__restrict__ partials, int m, int d,
-                                                           const T *__restrict__ ell, double *__restrict__ grad) {
-  __shared__ double red[NTHREADS];
+__global__ __launch_bounds__(RED_NT) void k_reduce_grad(const double *__restrict__ partials, int m, int d,
+                                                        const T *__restrict__ ell, double *__restrict__ grad) {
+  __shared__ double red[RED_NT];
   const int lat = blockIdx.x;
   const int ntile = m * m;
-  const int slot = threadIdx.x % GP;          // 34 slots; 256 / 34 = 7 groups (+ remainder idle)
+  const int slot = threadIdx.x % GP;
   const int grp = threadIdx.x / GP;
-  constexpr int NG = NTHREADS / GP;
-  double s = 0.0;
+  constexpr int NG = RED_NT / GP;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
   if (grp < NG) {
-    for (int t = grp; t < ntile; t += NG) {
-      int ib = t / m, jb = t % m;
-      if (jb >= ib) s += partials[((int64_t)lat * ntile + t) * GP + slot];
+    const double *base = partials + (int64_t)lat * ntile * GP + slot;
+    for (int t0 = grp; t0 < ntile; t0 += 4 * NG) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * NG;
+        if (t < ntile) {
+          const int ib = t / m, jb = t - ib * m;
+          if (jb >= ib) s[u] += base[(int64_t)t * GP];
+        }
+      }
     }
   }
-  red[threadIdx.x] = s;
+  red[threadIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
   __syncthreads();
   if (threadIdx.x < GP) {
     double tot = 0.0;
@@ -195,7 +204,7 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
 #undef PLMC_LAUNCH_KG
   {
     ProfScope ps(PK_REDUCE, st, 0.0, (double)plmc_grad_scratch_bytes(n_pad, q) / 2);
-    hipLaunchKernelGGL(k_reduce_grad<T>, dim3(q), dim3(NTHREADS), 0, st, part, m, d, ell, grad);
+    hipLaunchKernelGGL(k_reduce_grad<T>, dim3(q), dim3(RED_NT), 0, st, part, m, d, ell, grad);
   }
   return launch_status(__func__);
 }

@@ -121,6 +121,24 @@ def factorize_checked(kind, X, ell, oscale, noise, rhs, ws, Xs=None):
                        "(first failing pivot per latent: %s)" % (jit, info.tolist()))
 
 
+class _DeferredInfo:
+    """Pivot check of a factorisation without stalling the stream: `info` is copied to pinned host memory right
+    behind the sweep and looked at only after the kernels that follow it have been queued, so the GPU runs
+    from the sweep straight into them while the host waits for the copy (not for those kernels)."""
+
+    def __init__(self, ws):
+        if getattr(ws, "info_host", None) is None:
+            ws.info_host = torch.empty(ws.info.shape, dtype=ws.info.dtype, pin_memory=True)
+        self.host = ws.info_host
+        self.host.copy_(ws.info, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(ws.device))
+
+    def failed(self):
+        self.event.synchronize()
+        return bool(self.host.any())
+
+
 class ExactLatentLogProb(torch.autograd.Function):
     """log N(y_i; 0, os_i k(X,X; ell_i) + noise_i I) for a batch of q independent GPs, with the
     analytic gradient computed in the same pass.
@@ -143,17 +161,39 @@ class ExactLatentLogProb(torch.autograd.Function):
         Xc, ellc, osc, nzc, yc = (_contig(t, dt) for t in (X, ell, oscale, noise, y))
         ws = get_workspace(n, q, 1, dt, dev, need_grad)
         st = _hip.stream_ptr(dev)
-        jit = factorize_checked(kind, Xc, ellc, osc, nzc, yc.reshape(q, 1, n), ws)
-        L.call("plmc_extract_col", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, 0, _hip.ptr(ws.z),
-               _hip.ptr(ws.quad), q, st)
-        logp = -0.5 * (ws.quad + ws.logdet + n * LOG2PI)
+        grad = torch.empty(q, d + 2, dtype=torch.float64, device=dev) if need_grad else None
+        check = settings.check_cholesky.on()
+
+        def enqueue(noise_eff):
+            """factorisation + everything that consumes it; returns (logp, deferred pivot check)."""
+            factorize(kind, Xc, ellc, osc, noise_eff, yc.reshape(q, 1, n), ws)
+            info = _DeferredInfo(ws) if check else None
+            L.call("plmc_extract_col", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, 0, _hip.ptr(ws.z),
+                   _hip.ptr(ws.quad), q, st)
+            lp = -0.5 * (ws.quad + ws.logdet + n * LOG2PI)
+            if need_grad:
+                L.call("plmc_wt_matvec", dt, _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.z),
+                       _hip.ptr(ws.alpha), q, st)
+                L.call("plmc_kinv_grad", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW,
+                       _hip.ptr(ws.alpha), _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad),
+                       None, 0, 0, None, _hip.ptr(ws.partials), q, st)
+            return lp, info
+
+        # jitter ladder of gpytorch's psd_safe_cholesky [gpytorch-knowledge] (see factorize_checked)
+        logp, info = enqueue(nzc)
+        jit = 0.0
+        if check and info.failed():
+            base, tries = settings.cholesky_jitter.value(dt), settings.cholesky_max_tries.value()
+            for i in range(tries):
+                jit = base * (10 ** i)
+                warnings.warn("A not p.d., added jitter of %.1e to the diagonal" % jit, RuntimeWarning)
+                logp, info = enqueue(nzc + jit)
+                if not info.failed():
+                    break
+            else:
+                raise RuntimeError("Matrix not positive definite after repeatedly adding jitter up to %.1e "
+                                   "(first failing pivot per latent: %s)" % (jit, info.host.tolist()))
         if need_grad:
-            L.call("plmc_wt_matvec", dt, _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.z),
-                   _hip.ptr(ws.alpha), q, st)
-            grad = torch.empty(q, d + 2, dtype=torch.float64, device=dev)
-            L.call("plmc_kinv_grad", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW,
-                   _hip.ptr(ws.alpha), _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad),
-                   None, 0, 0, None, _hip.ptr(ws.partials), q, st)
             ctx.save_for_backward(grad, ws.alpha[:, :n].clone())
         ctx.d = d
         ctx.has_os = oscale is not None
