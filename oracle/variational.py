@@ -15,6 +15,10 @@ and `gp.mlls.VariationalELBO` (experiments.py:236) in plain torch-CPU.
   Gaussian expected_log_prob uses only marginal variances and the DIAGONAL of the task-noise
   covariance:  -1/2 sum_t [ ((y-mu)^2 + var) / s_t + log s_t + log 2pi ].
   VariationalELBO = (1/n) sum_points E_q[log p(y|f)]  -  KL / num_data.
+  UnwhitenedVariationalStrategy (selected at projected_lmc.py:724-729 when train_ind_ratio == 1, Z = train_x):
+     prior p(u) = N(0, Khat), Khat = K_ZZ + 1e-3 I (`add_jitter()` default);  q(u) = N(m, S);
+     x == Z: q(f) = q(u);  otherwise mean = K_xZ Khat^-1 m, cov = K_xx - K_xZ Khat^-1 K_Zx + K_xZ Khat^-1 S Khat^-1 K_Zx;
+     KL = KL(q(u) || p(u)) (closed form);  first call initialises q(u) to the prior.
 """
 import math
 
@@ -42,13 +46,35 @@ def latent_predictive(kind, X, Z, ell, var_mean, chol_var, nu=2.5, outputscale=N
     return mean_f, var_f, kl
 
 
+def unwhitened_latent_predictive(kind, X, Z, ell, var_mean, chol_var, nu=2.5, outputscale=None, jitter=1e-3):
+    """(mean_f (q,n), var_f (q,n), KL (q,)) of the q un-whitened variational GPs (see the module docstring)."""
+    m = Z.shape[0]
+    Khat = gm.kernel_matrix(kind, Z, Z, ell, outputscale, nu) + jitter * torch.eye(m, dtype=X.dtype)
+    Ls = chol_var.tril()
+    S = Ls @ Ls.transpose(-1, -2)
+    Kinv = torch.linalg.inv(Khat)
+    logdetK = torch.linalg.slogdet(Khat)[1]
+    logdetS = 2.0 * torch.log(torch.diagonal(Ls, dim1=-2, dim2=-1).abs()).sum(-1)
+    quad = (var_mean.unsqueeze(-2) @ Kinv @ var_mean.unsqueeze(-1)).reshape(-1)
+    kl = 0.5 * ((Kinv * S).sum((-2, -1)) + quad - m + logdetK - logdetS)
+    if X.shape == Z.shape and torch.equal(X, Z):
+        return var_mean, torch.diagonal(S, dim1=-2, dim2=-1), kl
+    Kzx = gm.kernel_matrix(kind, Z, X, ell, outputscale, nu)
+    B = Kinv @ Kzx
+    os_ = torch.ones(ell.shape[0], dtype=X.dtype) if outputscale is None else outputscale
+    mean_f = (B.transpose(-1, -2) @ var_mean.unsqueeze(-1)).squeeze(-1)
+    var_f = os_[:, None] - (Kzx * B).sum(-2) + ((Ls.transpose(-1, -2) @ B) ** 2).sum(-2)
+    return mean_f, var_f, kl
+
+
 def variational_elbo(kind, X, Y, Z, ell, var_mean, chol_var, H, task_noise_diag, task_means=None, nu=2.5,
-                     outputscale=None, jitter=1e-6, num_data=None):
+                     outputscale=None, jitter=1e-6, num_data=None, whitened=True):
     """VariationalELBO value (scalar).  H: (q,p); task_noise_diag: (p,) = diag of the task-noise covariance
     incl. global noise; task_means: (p,) constants or None."""
     n, p = Y.shape
     num_data = n if num_data is None else num_data
-    mean_f, var_f, kl = latent_predictive(kind, X, Z, ell, var_mean, chol_var, nu, outputscale, jitter)
+    pred = latent_predictive if whitened else unwhitened_latent_predictive
+    mean_f, var_f, kl = pred(kind, X, Z, ell, var_mean, chol_var, nu, outputscale, jitter)
     mu = mean_f.T @ H                                                        # (n,p)
     if task_means is not None:
         mu = mu + task_means.reshape(1, p)

@@ -108,3 +108,119 @@ class WhitenedInterp(torch.autograd.Function):
 
 def whitened_interp(kind, Z, X, ell, oscale, jitter):
     return WhitenedInterp.apply(Z, X, ell, oscale, kind, jitter)
+
+
+# ------------------------------------------------------------------------------------------------
+# Unwhitened strategy (train_ind_ratio == 1, projected_lmc.py:724-729): q(u) = N(m, Ls Ls^T) against the
+# prior N(0, Khat), Khat = K_ZZ + jitter I, with Z = the training inputs (n x n matrices per latent).
+class GaussianKLToKernelPrior(torch.autograd.Function):
+    """KL( N(m_i, Ls_i Ls_i^T) || N(0, Khat_i) ) = 1/2 [ tr(Khat^-1 S) + m^T Khat^-1 m - n + log det Khat - log det S ]
+    for q latent kernels, with the analytic gradient.
+
+    forward(Z (n,d), ell (q,d), oscale (q)|None, mvar (q,n), Ls (q,n,n) lower, kind, jitter) -> (q,)
+
+    One augmented sweep [Khat | m, Ls] gives U^-T [m, Ls] (trace and quadratic form are its squared norms),
+    log det Khat and W = U^-T.  Backward: Khat^-1 [m, Ls] = W^T (U^-T [m, Ls]) and
+    dKL/dKhat = 1/2 (Khat^-1 - (Khat^-1 [m, Ls]) (Khat^-1 [m, Ls])^T) are plain library GEMMs; the kernel-matrix
+    adjoint is pulled back to (Z, ell, oscale) by `plmc_kernel_vjp`."""
+
+    @staticmethod
+    def forward(ctx, Z, ell, oscale, mvar, Ls, kind, jitter):
+        _hip.require_device(Z, ell, mvar, Ls)
+        L = _hip.lib()
+        dt, dev = ell.dtype, ell.device
+        n, d = Z.shape
+        q = ell.shape[0]
+        Zc, ellc, osc = (_contig(t, dt) for t in (Z, ell, oscale))
+        rhs = torch.cat([mvar.detach().to(dt).unsqueeze(-1), torch.tril(Ls.detach().to(dt))], -1)     # (q, n, n+1)
+        rhs_t = rhs.transpose(-1, -2).contiguous()                                                  # write_rhs wants (q, nrhs, n)
+        ws = _workspace(n, q, n + 1, dt, dev, True)
+        st = _hip.stream_ptr(dev)
+        jit = torch.full((q,), float(jitter), dtype=dt, device=dev)
+        L.call("plmc_assemble", dt, _hip.KIND[kind], _hip.ptr(Zc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(jit),
+               _hip.ptr(ws.A), ws.lda, ws.strideA, q, st)
+        L.call("plmc_write_rhs", dt, _hip.ptr(rhs_t), n + 1, n, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, ws.naug_pad, q, st)
+        L.call("plmc_potrf", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, n + 1, ws.strideA, _hip.ptr(ws.Vd),
+               _hip.ptr(ws.logdet), _hip.ptr(ws.info), 1, q, st)
+        info = ws.info.cpu()
+        if bool(info.any()):
+            raise RuntimeError("K_ZZ + jitter not positive definite (first failing pivot per latent: %s)" % info.tolist())
+        Zs = ws.A[:, :n, ws.n_pad:ws.n_pad + n + 1]                                  # U^-T [m, Ls]
+        sq = (Zs.double() ** 2).sum(-2)                                              # (q, n+1) column norms
+        quad, tr = sq[:, 0], sq[:, 1:].sum(-1)
+        dg = torch.diagonal(Ls.detach(), dim1=-2, dim2=-1).double()
+        logdetS = 2.0 * torch.log(dg.abs()).sum(-1)
+        kl = 0.5 * (tr + quad - n + ws.logdet - logdetS)
+        W = torch.tril(ws.W[:, :n, :n])                                              # U^-T (lower)
+        ctx.save_for_backward(W, Zs.clone(), Zc, ellc, osc if osc is not None else torch.empty(0, device=dev), dg)
+        ctx.kind, ctx.has_os = kind, oscale is not None
+        return kl.to(dt)
+
+    @staticmethod
+    def backward(ctx, g):
+        W, Zs, Z, ell, osc, dg = ctx.saved_tensors
+        osc = osc if ctx.has_os else None
+        dt = W.dtype
+        Af = W.transpose(-1, -2) @ Zs                                                # Khat^-1 [m, Ls]   (q, n, n+1)
+        g_m = Af[..., 0]
+        g_Ls = torch.tril(Af[..., 1:]) - torch.diag_embed((1.0 / dg).to(dt))
+        Kinv = W.transpose(-1, -2) @ W
+        Gk = 0.5 * (Kinv - Af @ Af.transpose(-1, -2)) * g.to(dt)[:, None, None]
+        gZ, gE, gO = kernel_vjp(ctx.kind, Z, Z, ell, osc, Gk)
+        gl = g.to(dt)
+        return ((2.0 * gZ).to(dt), gE.to(dt), gO.to(dt) if ctx.has_os else None, gl[:, None] * g_m, gl[:, None, None] * g_Ls,
+                None, None)
+
+
+def gaussian_kl_to_kernel_prior(kind, Z, ell, oscale, mvar, Ls, jitter):
+    return GaussianKLToKernelPrior.apply(Z, ell, oscale, mvar, Ls, kind, jitter)
+
+
+def prior_cholesky(kind, Z, ell, oscale, jitter):
+    """Lower Cholesky factors of K_ZZ + jitter I (q, n, n), no gradient: the first-call initialisation of q(u)."""
+    L = _hip.lib()
+    dt, dev = ell.dtype, ell.device
+    n, d = Z.shape
+    q = ell.shape[0]
+    Zc, ellc, osc = (_contig(t, dt) for t in (Z, ell, oscale))
+    ws = _workspace(n, q, 0, dt, dev, False)
+    st = _hip.stream_ptr(dev)
+    jit = torch.full((q,), float(jitter), dtype=dt, device=dev)
+    L.call("plmc_assemble", dt, _hip.KIND[kind], _hip.ptr(Zc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(jit),
+           _hip.ptr(ws.A), ws.lda, ws.strideA, q, st)
+    L.call("plmc_potrf", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, 0, ws.strideA, _hip.ptr(ws.Vd), _hip.ptr(ws.logdet),
+           _hip.ptr(ws.info), 0, q, st)
+    if bool(ws.info.cpu().any()):
+        raise RuntimeError("K_ZZ + jitter not positive definite")
+    return torch.triu(ws.A[:, :n, :n]).transpose(-1, -2).contiguous()
+
+
+def unwhitened_predictive(kind, Z, X, ell, oscale, mvar, Ls, jitter):
+    """Marginal q(f(X)) for X != Z (eval mode), no gradient:  B = Khat^-1 K_ZX,
+    mean = B^T m,  var = k(x,x) - colsum((U^-T K_ZX)^2) + colsum((Ls^T B)^2)."""
+    L = _hip.lib()
+    dt, dev = ell.dtype, ell.device
+    n, d = Z.shape
+    ns = X.shape[0]
+    q = ell.shape[0]
+    Zc, Xc, ellc, osc = (_contig(t, dt) for t in (Z, X, ell, oscale))
+    ws = _workspace(n, q, ns, dt, dev, True)
+    st = _hip.stream_ptr(dev)
+    k = _hip.KIND[kind]
+    jit = torch.full((q,), float(jitter), dtype=dt, device=dev)
+    L.call("plmc_assemble", dt, k, _hip.ptr(Zc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(jit), _hip.ptr(ws.A),
+           ws.lda, ws.strideA, q, st)
+    L.call("plmc_write_rhs", dt, None, 0, n, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, ws.naug_pad, q, st)
+    L.call("plmc_assemble_cross", dt, k, _hip.ptr(Zc), n, _hip.ptr(Xc), ns, d, _hip.ptr(ellc), _hip.ptr(osc),
+           _hip.ptr(ws.A), ws.lda, ws.strideA, ws.n_pad, ws.n_pad, q, st)
+    L.call("plmc_potrf", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ns, ws.strideA, _hip.ptr(ws.Vd), _hip.ptr(ws.logdet),
+           _hip.ptr(ws.info), 1, q, st)
+    if bool(ws.info.cpu().any()):
+        raise RuntimeError("K_ZZ + jitter not positive definite")
+    C = ws.A[:, :n, ws.n_pad:ws.n_pad + ns]                                          # U^-T K_ZX
+    B = torch.tril(ws.W[:, :n, :n]).transpose(-1, -2) @ C                            # Khat^-1 K_ZX
+    mean = (B.transpose(-1, -2) @ mvar.to(dt).unsqueeze(-1)).squeeze(-1)
+    os_ = torch.ones(q, dtype=dt, device=dev) if osc is None else osc
+    LB = torch.tril(Ls.to(dt)).transpose(-1, -2) @ B
+    var = os_[:, None] - (C * C).sum(-2) + (LB * LB).sum(-2)
+    return mean, var

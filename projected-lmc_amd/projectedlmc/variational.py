@@ -35,10 +35,13 @@ class CholeskyVariationalDistribution(torch.nn.Module):
         eye = torch.eye(num_inducing_points).repeat(*batch_shape, 1, 1)
         self.register_parameter("chol_variational_covar", torch.nn.Parameter(eye))
 
-    def initialize_variational_distribution(self):
-        """q(u) <- whitened prior N(0, I) plus mean noise of std mean_init_std (first call only)."""
+    def initialize_variational_distribution(self, prior_chol=None):
+        """q(u) <- prior plus mean noise of std mean_init_std (first call only).  Whitened strategy: the prior is
+        N(0, I) (nothing to copy); unwhitened: `prior_chol` = Cholesky factor of the prior covariance."""
         with torch.no_grad():
             self.variational_mean.add_(self.mean_init_std * torch.randn_like(self.variational_mean))
+            if prior_chol is not None:
+                self.chol_variational_covar.copy_(prior_chol.to(self.chol_variational_covar.dtype))
 
 
 class VariationalStrategy(torch.nn.Module):
@@ -92,9 +95,42 @@ class VariationalStrategy(torch.nn.Module):
 
 
 class UnwhitenedVariationalStrategy(VariationalStrategy):
-    def __init__(self, *a, **k):
-        raise NotImplementedError("train_ind_ratio == 1 (UnwhitenedVariationalStrategy, inducing points = training "
-                                  "inputs, projected_lmc.py:724-729) is not built yet")
+    """q(u) = N(m, S) on the un-whitened inducing values; the reference selects it with inducing points = the
+    training inputs when `train_ind_ratio == 1` (projected_lmc.py:724-729).  gpytorch 1.11 semantics restated
+    [gpytorch-knowledge, unverified offline]:
+      * prior p(u) = N(mean(Z), K_ZZ + 1e-3 I)  (`lazy_covariance_matrix.add_jitter()` default);
+      * first call: q(u) <- the prior (mean + mean_init_std noise, Cholesky factor of the prior covariance);
+      * x equal to the inducing points: q(f) = q(u) itself; otherwise the usual marginalisation
+        mean = K_xZ Khat^-1 m,  cov = K_xx - K_xZ Khat^-1 K_Zx + K_xZ Khat^-1 S Khat^-1 K_Zx;
+      * KL = KL(q(u) || p(u)) in closed form.
+    The n x n factorisations run on the HIP sweep (_var_engine.GaussianKLToKernelPrior)."""
+
+    PRIOR_JITTER = 1e-3
+
+    def latent_moments(self, x):
+        model = self.model
+        kern = model.covar_module
+        Z = self.inducing_points
+        kind, ell, osc = kern._pieces(Z.shape[-1])
+        dt = ell.dtype
+        jit = self.jitter_val if self.jitter_val is not None else self.PRIOR_JITTER
+        vd = self._variational_distribution
+        Zs = kern.select(Z)
+        if not bool(self.variational_params_initialized.item()):
+            with torch.no_grad():
+                Lp = _var_engine.prior_cholesky(kind, Zs, ell, osc, jit)
+            vd.initialize_variational_distribution(prior_chol=Lp)
+            self.variational_params_initialized.fill_(1)
+        mvar = vd.variational_mean.to(dt)
+        Ls = vd.chol_variational_covar.to(dt).tril()
+        kl = _var_engine.gaussian_kl_to_kernel_prior(kind, Zs, ell, osc, mvar, Ls, jit)
+        if x.shape == Z.shape and torch.equal(x, Z):
+            return mvar, (Ls * Ls).sum(-1), kl
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (ell, mvar, Ls)):
+            raise NotImplementedError("UnwhitenedVariationalStrategy: gradients are built for x == inducing points (the "
+                                      "reference's training call); evaluate other inputs under torch.no_grad()")
+        mean_f, var_f = _var_engine.unwhitened_predictive(kind, Zs, kern.select(x), ell, osc, mvar, Ls, jit)
+        return mean_f, var_f, kl
 
 
 class LMCVariationalStrategy(torch.nn.Module):

@@ -102,3 +102,113 @@ def test_elbo_fp32_config4_shape(plmc):
     with torch.no_grad():
         pred = lik(model(X[:50].to(DEV)))
     assert pred.mean.shape == (50, p) and bool((pred.variance > 0).all())
+
+
+# ------------------------------------------------------------------------------------------------
+# train_ind_ratio == 1: UnwhitenedVariationalStrategy with inducing points = training inputs
+# (projected_lmc.py:724-729)
+def _build_unwhitened(plmc, n, d, p, q, kernel, oscale, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    X = 2 * torch.rand(n, d, generator=g, dtype=torch.float64) - 1
+    Y = torch.randn(n, p, generator=g, dtype=torch.float64)
+    torch.manual_seed(seed)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        lik = plmc.MultitaskGaussianLikelihood(num_tasks=p, rank=2)
+        with pytest.warns(UserWarning, match="inducing points not learned"):
+            model = plmc.VariationalMultitaskGPModel(X, n_latents=q, n_tasks=p, train_ind_ratio=1.0, seed=0,
+                                                     init_lmc_coeffs=True, train_y=Y, mean_type=plmc.ConstantMean,
+                                                     kernel_type=getattr(plmc, kernel), outputscales=oscale)
+    finally:
+        torch.set_default_dtype(old)
+    return X, Y, model, lik
+
+
+def _perturb(model, lik, seed):
+    g2 = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, prm in list(model.named_parameters()) + list(lik.named_parameters()):
+            prm.add_(0.1 * torch.randn(prm.shape, generator=g2, dtype=torch.float64).to(prm.dtype))
+
+
+def _oracle_elbo_unwhitened(model, lik, X, Y, kind, nu, Xeval=None):
+    sd = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in
+          list(model.named_parameters()) + [("lik." + k, v) for k, v in lik.named_parameters()]}
+    b = "variational_strategy.base_variational_strategy."
+    has_os = "covar_module.raw_outputscale" in sd
+    ell = gm.softplus(sd["covar_module.base_kernel.raw_lengthscale" if has_os else "covar_module.raw_lengthscale"])
+    ell = ell.reshape(ell.shape[0], -1)
+    osc = gm.softplus(sd["covar_module.raw_outputscale"]) if has_os else None
+    F = sd["lik.task_noise_covar_factor"]
+    noise_diag = (F * F).sum(-1) + gm.softplus(sd["lik.raw_noise"]).reshape(()) + 1e-4
+    Z = model.variational_strategy.base_variational_strategy.inducing_points.detach().cpu().double()
+    val = ov.variational_elbo(kind, X.double(), Y.double(), Z, ell,
+                              sd[b + "_variational_distribution.variational_mean"],
+                              sd[b + "_variational_distribution.chol_variational_covar"],
+                              sd["variational_strategy.lmc_coefficients"], noise_diag,
+                              task_means=sd["variational_strategy.output_mean_module.raw_constant"],
+                              nu=nu, outputscale=osc, jitter=1e-3, num_data=X.shape[0], whitened=False)
+    return val, sd, (ell, osc, Z)
+
+
+@pytest.mark.parametrize("kernel,oscale", [("RBFKernel", False), ("MaternKernel", True)])
+def test_unwhitened_elbo_and_all_gradients_fp64(plmc, kernel, oscale):
+    n, d, p, q = 140, 2, 3, 2
+    X, Y, model, lik = _build_unwhitened(plmc, n, d, p, q, kernel, oscale)
+    kind, nu = ("rbf", 2.5) if kernel == "RBFKernel" else ("matern", 2.5)
+    bvs = model.variational_strategy.base_variational_strategy
+    assert type(bvs).__name__ == "UnwhitenedVariationalStrategy"
+    assert "inducing_points" not in dict(bvs.named_parameters())            # not learned (:727)
+    model, lik = model.to(DEV), lik.to(DEV)
+    model.train(); lik.train()
+    mll = plmc.VariationalELBO(lik, model, num_data=n)
+    # first call initialises q(u) to the prior: chol_variational_covar <- chol(K_ZZ + 1e-3 I)
+    with torch.no_grad():
+        mll(model(X.to(DEV)), Y.to(DEV))
+    ell0 = model.covar_module.base_kernel.lengthscale if oscale else model.covar_module.lengthscale
+    osc0 = model.covar_module.outputscale.detach().cpu().double() if oscale else None
+    K0 = gm.kernel_matrix(kind, X, X, ell0.detach().cpu().double().reshape(q, d), osc0, nu) + 1e-3 * torch.eye(n, dtype=torch.float64)
+    Ls0 = bvs._variational_distribution.chol_variational_covar.detach().cpu()
+    assert torch.allclose(Ls0 @ Ls0.transpose(-1, -2), K0, rtol=1e-9, atol=1e-11)
+    # now an arbitrary point of parameter space
+    model, lik = model.cpu(), lik.cpu()
+    _perturb(model, lik, 5)
+    ref, sd, _ = _oracle_elbo_unwhitened(model, lik, X, Y, kind, nu)
+    ref.backward()
+    model, lik = model.to(DEV), lik.to(DEV)
+    out = mll(model(X.to(DEV)), Y.to(DEV))
+    out.backward()
+    assert abs(float(out.detach()) - float(ref.detach())) < 1e-9 * abs(float(ref.detach())), (float(out), float(ref))
+    named = dict(list(model.named_parameters()) + [("lik." + k, v) for k, v in lik.named_parameters()])
+    for name, leaf in sd.items():
+        if leaf.grad is None:
+            continue
+        got, ref_g = named[name].grad, leaf.grad
+        assert got is not None, name
+        if name.endswith("chol_variational_covar"):
+            got, ref_g = got.cpu().tril(), ref_g.tril()
+        assert torch.allclose(got.cpu(), ref_g, rtol=2e-5, atol=1e-8), (name, (got.cpu() - ref_g).abs().max())
+
+
+def test_unwhitened_eval_predictions_fp64(plmc):
+    n, d, p, q, ns = 120, 2, 3, 2, 17
+    X, Y, model, lik = _build_unwhitened(plmc, n, d, p, q, "MaternKernel", False, seed=2)
+    model.variational_strategy.base_variational_strategy.variational_params_initialized.fill_(1)
+    _perturb(model, lik, 9)
+    g = torch.Generator().manual_seed(11)
+    Xs = 2 * torch.rand(ns, d, generator=g, dtype=torch.float64) - 1
+    _, sd, (ell, osc, Z) = _oracle_elbo_unwhitened(model, lik, X, Y, "matern", 2.5)
+    b = "variational_strategy.base_variational_strategy."
+    with torch.no_grad():
+        mean_f, var_f, _ = ov.unwhitened_latent_predictive("matern", Xs, Z, ell, sd[b + "_variational_distribution.variational_mean"],
+                                                           sd[b + "_variational_distribution.chol_variational_covar"], 2.5, osc, 1e-3)
+        H = sd["variational_strategy.lmc_coefficients"]
+        mu_ref = mean_f.T @ H + sd["variational_strategy.output_mean_module.raw_constant"].reshape(1, p)
+        var_ref = var_f.T @ (H * H)
+    model = model.to(DEV)
+    model.eval()
+    with torch.no_grad():
+        dist = model(Xs.to(DEV))
+    assert torch.allclose(dist.mean.cpu(), mu_ref, rtol=1e-8, atol=1e-10)
+    assert torch.allclose(dist.variance.cpu(), var_ref, rtol=1e-7, atol=1e-10)
