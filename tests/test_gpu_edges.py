@@ -155,3 +155,25 @@ def test_metric_shape_properties_fp32(eng):
     perm = torch.randperm(n, generator=g).to(DEV)
     lp_perm = eng.exact_latent_log_prob("matern52", X[perm], ell, osc, noise, y[:, perm])
     assert torch.allclose(lp.detach(), lp_perm, rtol=2e-5)
+
+
+def test_sarcos_scale_single_latent_fp32(eng):
+    """One rank's share of BASELINE config 5 (n = 44484, d = 21, one latent per GPU, Matern-5/2, fp32; 16 GB factor
+    buffer): the engine runs at that size (64-bit offsets, 348 block rows) and the outputs satisfy the linearity /
+    Euler identity of the Gaussian log-density: logp(y/2) - logp(y) = 3/8 * y.(Khat^-1 y)."""
+    n, d, q = 44484, 21, 1
+    g = torch.Generator().manual_seed(0)
+    X = (2 * torch.rand(n, d, generator=g) - 1).to(DEV)
+    y = torch.randn(q, n, generator=g).to(DEV)
+    ell = torch.full((q, d), 1.5, device=DEV)
+    noise = torch.tensor([0.5], device=DEV)
+    yg = y.clone().requires_grad_()
+    lp = eng.exact_latent_log_prob("matern52", X, ell, None, noise, yg)
+    lp.sum().backward()
+    assert bool(torch.isfinite(lp).all())
+    quad = -(yg.grad * y).sum(-1)
+    assert bool((quad > 0).all())
+    lp_half = eng.exact_latent_log_prob("matern52", X, ell, None, noise, 0.5 * y)
+    assert torch.allclose(lp_half - lp.detach(), 0.375 * quad, rtol=1e-4)
+    eng.free_workspaces()
+    torch.cuda.empty_cache()
