@@ -58,13 +58,26 @@ class LMCMixingMatrix(torch.nn.Module):
         return self.Q_plus[:, self.n_latents:]
 
     def QR(self):
+        """(Q, R, Q_orth).  Bulk mode re-factors H at every call in the reference (:864-875), and a training step
+        calls it twice on the same H (projection :1015, MLL terms :1208); the factorisation is ~60 tiny
+        device kernels plus their backward, so the result is reused while H is unchanged (same tensor
+        version, same grad mode) -- identical values, one autograd node feeding both uses."""
         q = self.n_latents
         if self.bulk:
-            Qf, Rf = torch.linalg.qr(self.H)
+            key = (self.H._version, self.H.data_ptr(), torch.is_grad_enabled(), self.H.dtype, self.H.device)
+            cached = getattr(self, "_qr_cache", None)
+            if cached is None or cached[0] != key:
+                Qf, Rf = torch.linalg.qr(self.H)
+                cached = (key, Qf, Rf)
+                object.__setattr__(self, "_qr_cache", cached)
+            _, Qf, Rf = cached
             if self.mode == 'Q_plus':
                 return Qf[:, :q], Rf[:q, :q], Qf[:, q:]
             return Qf, Rf, None
         return self.Q(), self.R, self.Q_orth()
+
+    def drop_qr_cache(self):
+        object.__setattr__(self, "_qr_cache", None)
 
     def forward(self):
         if self.bulk:
@@ -338,6 +351,7 @@ class ProjectedLMCmll(ExactMarginalLogLikelihood):
         p, q = model.n_tasks, model.n_latents
         self.proj_term_list = [0] * 3
         Q, R, Q_orth = model.lmc_coefficients.QR()
+        model.lmc_coefficients.drop_qr_cache()              # last use in a training step: do not outlive the graph
         if not hasattr(model, 'M') and model.scalar_B:
             if model.log_B_tilde.numel() > 0:
                 lb = model.log_B_tilde
