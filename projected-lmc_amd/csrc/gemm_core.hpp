@@ -59,6 +59,10 @@ template <typename T> struct Acc {
   }
 };
 
+// Occupancy floor of the tile kernels (second __launch_bounds__ argument = waves per SIMD): the fp64 kernels need
+// 128 accumulator registers; without a floor hipcc spends 230+ more and leaves one wave per SIMD.
+template <typename T> constexpr int TILE_MIN_WAVES = sizeof(T) == 8 ? 2 : 1;
+
 // LDS needed by tile_mainloop: 2 stages x (A,B) x BK x LDT elements.
 template <typename T> constexpr int tile_smem_elems() { return 2 * 2 * BK * LDT; }
 
@@ -166,20 +170,26 @@ __device__ __forceinline__ void tile_writeback(const Acc<T> &acc, T *Cg, int64_t
         }
     }
     __syncthreads();
-    vec_t v[NCH];
-    if (ADD) {
+    // chunks are moved SUB at a time: all 16 fp64 chunks in flight at once cost 64 more registers than the
+    // main loop needs and halved the occupancy of every fp64 tile kernel
+    constexpr int SUB = sizeof(T) == 8 ? 4 : NCH;
 #pragma unroll
-      for (int h = 0; h < NCH; ++h) {
-        const int c = tid + h * NTHREADS, row = c / CPR, col = (c % CPR) * EPV;
-        v[h] = *reinterpret_cast<const vec_t *>(Cg + (int64_t)(half * 64 + row) * ldc + col);
+    for (int h0 = 0; h0 < NCH; h0 += SUB) {
+      vec_t v[SUB];
+      if (ADD) {
+#pragma unroll
+        for (int h = 0; h < SUB; ++h) {
+          const int c = tid + (h0 + h) * NTHREADS, row = c / CPR, col = (c % CPR) * EPV;
+          v[h] = *reinterpret_cast<const vec_t *>(Cg + (int64_t)(half * 64 + row) * ldc + col);
+        }
       }
-    }
 #pragma unroll
-    for (int h = 0; h < NCH; ++h) {
-      const int c = tid + h * NTHREADS, row = c / CPR, col = (c % CPR) * EPV;
-      const vec_t s = *reinterpret_cast<const vec_t *>(smem + row * LDW + col);
-      vec_t o = ADD ? v[h] + s : s;
-      *reinterpret_cast<vec_t *>(Cg + (int64_t)(half * 64 + row) * ldc + col) = o;
+      for (int h = 0; h < SUB; ++h) {
+        const int c = tid + (h0 + h) * NTHREADS, row = c / CPR, col = (c % CPR) * EPV;
+        const vec_t s = *reinterpret_cast<const vec_t *>(smem + row * LDW + col);
+        vec_t o = ADD ? v[h] + s : s;
+        *reinterpret_cast<vec_t *>(Cg + (int64_t)(half * 64 + row) * ldc + col) = o;
+      }
     }
   }
 }

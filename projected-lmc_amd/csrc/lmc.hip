@@ -119,7 +119,7 @@ __global__ __launch_bounds__(NTHREADS) void k_lmc_cross(int kind, const T *__res
 __host__ __device__ inline int lmc_nacc(int p, int q, int d) { return q * p * p + q * d + q + p * p; }
 
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_lmc_kinv_grad(int kind, const T *__restrict__ W, int64_t N_pad, int64_t ldw,
+__global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_lmc_kinv_grad(int kind, const T *__restrict__ W, int64_t N_pad, int64_t ldw,
                                                              const T *__restrict__ alpha, const T *__restrict__ X,
                                                              int n, int d, int p, int q, const T *__restrict__ ell,
                                                              const T *__restrict__ oscale, const T *__restrict__ B,

@@ -34,7 +34,7 @@ struct ColMap {
 
 // Row panel solve P <- V_rr^T P for block row r.  grid (nU + Taug + nW, q).
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_panel(T *A, int64_t lda, int64_t strideA, int r, ColMap cm,
+__global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_panel(T *A, int64_t lda, int64_t strideA, int r, ColMap cm,
                                                      const T *__restrict__ Vd, int64_t strideV) {
   __builtin_amdgcn_s_setprio(3);       // chain kernel: ahead of the concurrently running trailing update
   __shared__ __align__(16) T smem[tile_smem_elems<T>()];
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(NTHREADS) void k_panel(T *A, int64_t lda, int64_t s
 // raised wave priority), 2 = the "head" rows the next group needs.  Separate symbols keep the three launch
 // shapes apart in kernel traces and counter passes.
 template <typename T, int ROLE>
-__global__ __launch_bounds__(NTHREADS) void k_update(T *A, int64_t lda, int64_t strideA, int ib0, int r_lo, int r_hi,
+__global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, int64_t lda, int64_t strideA, int ib0, int r_lo, int r_hi,
                                                       ColMap cm) {
   if (ROLE == 1) __builtin_amdgcn_s_setprio(3);
   // plain row-major tile order: an XCD-dealt super-block order (as k_kinv_grad uses) was 3 % faster for a

@@ -16,7 +16,7 @@ namespace plmc {
 constexpr int GP = MAX_DIM + 2;      // partial-sum slots per tile: d lengthscales, noise, outputscale
 
 template <typename T, int DCAP>
-__global__ __launch_bounds__(NTHREADS) void k_kinv_grad(int kind, const T *__restrict__ W, int64_t n_pad, int64_t ldw,
+__global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_kinv_grad(int kind, const T *__restrict__ W, int64_t n_pad, int64_t ldw,
                                                          int64_t strideW, const T *__restrict__ alpha,
                                                          const T *__restrict__ X, int n, int d,
                                                          const T *__restrict__ ell, const T *__restrict__ oscale,
