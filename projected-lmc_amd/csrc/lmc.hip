@@ -118,7 +118,11 @@ __global__ __launch_bounds__(NTHREADS) void k_lmc_cross(int kind, const T *__res
 // Number of fp64 accumulators per tile: [q*p*p dB | q*d d ell | q d os | p*p dSigma].
 __host__ __device__ inline int lmc_nacc(int p, int q, int d) { return q * p * p + q * d + q + p * p; }
 
-template <typename T>
+// The epilogue walks the tile once per latent: the lengthscale / outputscale sums of that latent (the same d + 1
+// addresses for every element) stay in per-lane registers and are flushed to the LDS accumulators once per latent;
+// with every lane adding to the same LDS words per element the fp64 LDS atomics serialised 64-fold.  The
+// (task, task) scatter of dB and dSigma stays on LDS atomics (different lanes hit different words).
+template <typename T, int DCAP>
 __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_lmc_kinv_grad(int kind, const T *__restrict__ W, int64_t N_pad, int64_t ldw,
                                                              const T *__restrict__ alpha, const T *__restrict__ X,
                                                              int n, int d, int p, int q, const T *__restrict__ ell,
@@ -151,65 +155,84 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_lmc_kinv_grad(i
   __syncthreads();
   const int64_t N = (int64_t)n * p;
   const int ldu = d + 1;
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-      const int row = tile_row<T>(wm, mt, lane, r);
-      const int64_t I = (int64_t)ib * NB + row;
-      const int a = (int)(I / p), s = (int)(I % p);
-      const T a_i = ai[row];
+  for (int i = 0; i < q; ++i) {
+    T gl[DCAP], go = T(0);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int col = tile_col(wn, nt, lane);
-        const int64_t J = (int64_t)jb * NB + col;
-        const auto &av = acc.v[mt][nt];
-        const T kin = r == 0 ? av[0] : (r == 1 ? av[1] : (r == 2 ? av[2] : av[3]));
-        if (I < N && J < N && J >= I) {
-          const int b = (int)(J / p), tt = (int)(J % p);
-          const T wij = (I == J ? T(1) : T(2)) * (a_i * aj[col] - kin);
-          if (a == b) atomicAdd(&gS[s * p + tt], (double)wij);
-          for (int i = 0; i < q; ++i) {
+    for (int k = 0; k < DCAP; ++k) gl[k] = T(0);
+    const T os_i = t.os[i];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll 1
+      for (int r = 0; r < 4; ++r) {
+        const int row = tile_row<T>(wm, mt, lane, r);
+        const int64_t I = (int64_t)ib * NB + row;
+        const int a = (int)(I / p), s = (int)(I % p);
+        const T a_i = ai[row];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int col = tile_col(wn, nt, lane);
+          const int64_t J = (int64_t)jb * NB + col;
+          const auto &av = acc.v[mt][nt];
+          const T kin = r == 0 ? av[0] : (r == 1 ? av[1] : (r == 2 ? av[2] : av[3]));
+          if (I < N && J < N && J >= I) {
+            const int b = (int)(J / p), tt = (int)(J % p);
+            const T wij = (I == J ? T(1) : T(2)) * (a_i * aj[col] - kin);
+            if (i == 0 && a == b) atomicAdd(&gS[s * p + tt], (double)wij);
+            T dfs[DCAP];
             T r2 = T(0);
-            for (int k = 0; k < d; ++k) {
-              T df = (t.xi[row * ldu + k] - t.xj[col * ldu + k]) * t.invl[i * d + k];
-              r2 += df * df;
+#pragma unroll
+            for (int k = 0; k < DCAP; ++k) {
+              const T df = k < d ? (t.xi[row * ldu + k] - t.xj[col * ldu + k]) * t.invl[i * d + k] : T(0);
+              dfs[k] = df * df;
+              r2 += dfs[k];
             }
             T val, base;
             kern_value_base<T>(kind, r2, val, base);
             const T bst = t.B[(i * p + s) * p + tt];
-            atomicAdd(&gB[(i * p + s) * p + tt], (double)(wij * t.os[i] * val));
-            atomicAdd(&gO[i], (double)(wij * val * bst));
-            if (a != b) {
-              const T c = wij * t.os[i] * bst * base;
-              for (int k = 0; k < d; ++k) {
-                T df = (t.xi[row * ldu + k] - t.xj[col * ldu + k]) * t.invl[i * d + k];
-                atomicAdd(&gL[i * d + k], (double)(c * df * df));
-              }
-            }
+            atomicAdd(&gB[(i * p + s) * p + tt], (double)(wij * os_i * val));
+            go += wij * val * bst;
+            const T c = a != b ? wij * os_i * bst * base : T(0);
+#pragma unroll
+            for (int k = 0; k < DCAP; ++k) gl[k] += c * dfs[k];
           }
         }
       }
     }
+    atomicAdd(&gO[i], (double)go);
+#pragma unroll
+    for (int k = 0; k < DCAP; ++k)
+      if (k < d) atomicAdd(&gL[i * d + k], (double)gl[k]);
   }
   __syncthreads();
   double *out = partials + ((int64_t)ib * m + jb) * nacc;
   for (int e = tid; e < nacc; e += NTHREADS) out[e] = accs[e];
 }
 
-// grad[e] = 1/2 sum over upper tiles (fixed order); lengthscale entries additionally / ell.  grid (ceil(nacc/256)).
+// grad[e] = 1/2 sum over upper tiles (fixed order); lengthscale entries additionally / ell.
+// grid (nacc), 256 threads striding over the m^2 tile slots, fixed-order tree reduction.
 template <typename T>
-__global__ void k_lmc_reduce(const double *__restrict__ partials, int m, int nacc, int p, int q, int d,
-                             const T *__restrict__ ell, double *__restrict__ grad) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nacc) return;
+__global__ __launch_bounds__(NTHREADS) void k_lmc_reduce(const double *__restrict__ partials, int m, int nacc, int p, int q,
+                                                          int d, const T *__restrict__ ell, double *__restrict__ grad) {
+  __shared__ double red[NTHREADS];
+  const int e = blockIdx.x;
   double s = 0.0;
-  for (int ib = 0; ib < m; ++ib)
-    for (int jb = ib; jb < m; ++jb) s += partials[((int64_t)ib * m + jb) * nacc + e];
-  s *= 0.5;
-  const int l0 = q * p * p;
-  if (e >= l0 && e < l0 + q * d) s /= (double)ell[e - l0];
-  grad[e] = s;
+  for (int t = threadIdx.x; t < m * m; t += NTHREADS) {
+    const int ib = t / m, jb = t - ib * m;
+    if (jb >= ib) s += partials[(int64_t)t * nacc + e];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = NTHREADS / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double v = 0.5 * red[0];
+    const int l0 = q * p * p;
+    if (e >= l0 && e < l0 + q * d) v /= (double)ell[e - l0];
+    grad[e] = v;
+  }
 }
 
 template <typename T> size_t lmc_stage_elems(int p, int q, int d) {
@@ -261,20 +284,27 @@ int lmc_kinv_grad_impl(int kind, const T *W, int64_t N_pad, int64_t ldw, const T
   size_t smem = (size_t)tile_smem_elems<T>() * sizeof(T);
   if (epi > smem) smem = epi;
   PLMC_REQUIRE(smem <= 150 * 1024, "q*p*p too large for the LDS accumulators");
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lmc_kinv_grad<T>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipStream_t st = (hipStream_t)stream;
   const int m = (int)(N_pad / NB);
   double *part = reinterpret_cast<double *>(partials);
   {
     const double np = (double)N_pad;
     ProfScope ps(PK_KINV_GRAD, st, np * np * np / 3.0, (np * np / 2) * sizeof(T));
-    hipLaunchKernelGGL(k_lmc_kinv_grad<T>, dim3(m, m), dim3(NTHREADS), smem, st, kind, W, N_pad, ldw, alpha, X, n, d, p,
-                       q, ell, oscale, B, part);
+#define PLMC_LAUNCH_LKG(DC)                                                                                              \
+  do {                                                                                                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lmc_kinv_grad<T, DC>),                                    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                     \
+    hipLaunchKernelGGL((k_lmc_kinv_grad<T, DC>), dim3(m, m), dim3(NTHREADS), smem, st, kind, W, N_pad, ldw, alpha, X, n,  \
+                       d, p, q, ell, oscale, B, part);                                                                    \
+  } while (0)
+    if (d <= 8) PLMC_LAUNCH_LKG(8);
+    else if (d <= 16) PLMC_LAUNCH_LKG(16);
+    else PLMC_LAUNCH_LKG(32);
+#undef PLMC_LAUNCH_LKG
   }
   {
     ProfScope ps(PK_REDUCE, st, 0.0, (double)m * m / 2 * nacc * 8);
-    hipLaunchKernelGGL(k_lmc_reduce<T>, dim3((nacc + 255) / 256), dim3(256), 0, st, part, m, nacc, p, q, d, ell, grad);
+    hipLaunchKernelGGL(k_lmc_reduce<T>, dim3(nacc), dim3(NTHREADS), 0, st, part, m, nacc, p, q, d, ell, grad);
   }
   return launch_status(__func__);
 }
