@@ -274,14 +274,17 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     }
   };
   // Look-ahead on two streams.  C (helper, high priority) carries the latency-bound work: the chain of
-  // each group and the "head" update (the block rows the NEXT chain needs); T carries the "tail"
-  // update of all other rows (CU-masked so that a few CUs always have LDS / wave slots free for C).
+  // each group and the "head" update (the block rows the NEXT chain needs); T (the caller's stream) carries the
+  // "tail" update of all other rows.
   //   head(g) needs chain(g) [same stream] and tail(g-1) [event, normally long complete];
   //   tail(g) needs chain(g) [event] and tail(g-1) [same stream]; head(g) and tail(g) touch disjoint rows.
   // C never waits on an event that is still pending when the chain is the bottleneck (few latents), and T
   // runs its updates back to back when the updates are (many latents).  Falls back to one stream.
   hipStream_t C = side_stream();
-  hipStream_t s2 = getenv("PLMC_NO_CUMASK") ? nullptr : tail_stream(8);
+  // dev knob PLMC_CUMASK=1: tail on a CU-masked stream (one CU per XCD kept free for the chain).  It paid when a
+  // diagonal-block workgroup needed 66 KB of LDS + 16 wave slots at once (2 % then); with the 19 KB / 8-wave
+  // kernel the tail is better off with all CUs (42.9 vs 43.5 ms/step), so the default is the caller's stream.
+  hipStream_t s2 = getenv("PLMC_CUMASK") ? tail_stream(8) : nullptr;
   hipEvent_t e_chain = sync_event(0), e_tail = sync_event(1), e_entry = sync_event(2), e_done = sync_event(3);
   const bool la = C && e_chain && e_tail && e_entry && e_done && ng > 2 && !getenv("PLMC_SERIAL");   // dev knob: one stream
   if (!la) {

@@ -51,7 +51,7 @@ def test_logprob_and_grad_fp64(eng, kind, n, d, q, use_os):
         assert torch.allclose(os_d.grad.cpu(), w * ref[3], rtol=1e-7, atol=1e-9)
 
 
-@pytest.mark.parametrize("n,d,q,env", [(1300, 3, 2, None), (2100, 4, 8, None), (1300, 3, 2, "PLMC_SERIAL"), (1300, 3, 2, "PLMC_NO_CUMASK")])
+@pytest.mark.parametrize("n,d,q,env", [(1300, 3, 2, None), (2100, 4, 8, None), (1300, 3, 2, "PLMC_SERIAL"), (1300, 3, 2, "PLMC_CUMASK")])
 def test_multi_group_sweep_fp64(eng, n, d, q, env, monkeypatch):
     """Sizes at which the sweep runs its look-ahead schedule (more than two groups of block rows, head / tail
     updates on separate streams, group sizes 4 and 8 + ramp-down), against the dense fp64 oracle; also with the
