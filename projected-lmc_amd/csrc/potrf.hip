@@ -240,7 +240,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   {
     const char *genv = getenv("PLMC_GRP");                // dev knob: fixed group size
     const int fixed = genv ? atoi(genv) : 0;
-    const int big = fixed > 0 ? fixed : ((q >= 8 && m >= 32) ? 8 : 4);
+    const int big = fixed > 0 ? fixed : ((q >= 8 && m >= 32) ? 8 : (q == 1 ? 3 : 4));   // measured per q on MI355X
     int r = 0;
     gb.push_back(0);
     const char *senv = getenv("PLMC_GRP_SCHED");          // dev knob: explicit comma-separated group sizes
