@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace plmc {
 
@@ -72,11 +73,19 @@ template <typename T> __device__ __forceinline__ int tile_row(int wm, int mt, in
 }
 __device__ __forceinline__ int tile_col(int wn, int nt, int lane) { return wn * 64 + nt * 16 + (lane & 15); }
 
-// acc += (negate ? -1 : 1) * sum_{k < K} Ag[k][0..127]^T * Bg[k][0..127]
+// acc += sum_{k < K} Ag[k][0..127]^T * Bg[k][0..127]      (NEG: the A fragments are negated -- dev benches only;
+// the product kernels subtract in the epilogue instead, tile_writeback<.., WB_SUB>)
 // Ag/Bg point at the first row of the K range and the first of the 128 columns; K % BK == 0.
 // All 256 threads must call it; ends with a barrier (LDS free for reuse on return).
 // REV walks the K range from its last BK-slab to its first: tiles whose ranges END together then
 // read the same operand rows at the same time (L2 sharing for the triangular products).
+//
+// Everything that is not an MFMA is kept off the vector ALU inside the loop: non-MFMA VALU instructions
+// compete with the MFMAs of the co-resident waves for the SIMD's issue port (SQ counters on a plain 8192^3
+// GEMM: 0.58 VALU per MFMA -> 130 TF; pointer-increment global addresses alone -> 141 TF).  Global addresses
+// advance by pointer increments, LDS positions are loop-invariant registers plus one stage offset per slab, and the
+// sign of C -= A^T B is applied in the epilogue.  (Unrolling the slab loop by two to make the stage a compile-time
+// constant cost 50 more registers and an occupancy step: 128 TF.)
 template <typename T, bool NEG, bool REV = false>
 __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__ Ag, int64_t lda,
                                               const T *__restrict__ Bg, int64_t ldb, int K, T *smem) {
@@ -85,6 +94,7 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
   constexpr int EPV = Tr::EPV;
   constexpr int CPR = 128 / EPV;                     // 16-byte chunks per tile row
   constexpr int NCH = BK * CPR / NTHREADS;           // chunks per thread per operand (2 / 4)
+  constexpr int RSTEP = NTHREADS / CPR;              // rows between a thread's chunks (8 / 4)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -94,42 +104,47 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
 
   vec_t ra[NCH], rb[NCH];
   const int nkt = K / BK;
-  auto gload = [&](int kt) {
-    if (REV) kt = nkt - 1 - kt;
+  const int row0 = tid / CPR, col0 = (tid % CPR) * EPV;
+  const T *ga = Ag + (int64_t)((REV ? (nkt - 1) * BK : 0) + row0) * lda + col0;
+  const T *gb = Bg + (int64_t)((REV ? (nkt - 1) * BK : 0) + row0) * ldb + col0;
+  const int64_t stepA = (REV ? -(int64_t)BK : (int64_t)BK) * lda, stepB = (REV ? -(int64_t)BK : (int64_t)BK) * ldb;
+  const int64_t rsA = (int64_t)RSTEP * lda, rsB = (int64_t)RSTEP * ldb;
+  auto gload = [&]() {
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
-      int c = tid + h * NTHREADS;
-      int row = c / CPR, col = (c % CPR) * EPV;
-      ra[h] = *reinterpret_cast<const vec_t *>(Ag + (int64_t)(kt * BK + row) * lda + col);
-      rb[h] = *reinterpret_cast<const vec_t *>(Bg + (int64_t)(kt * BK + row) * ldb + col);
+      ra[h] = *reinterpret_cast<const vec_t *>(ga + h * rsA);
+      rb[h] = *reinterpret_cast<const vec_t *>(gb + h * rsB);
     }
+    ga += stepA;
+    gb += stepB;
   };
+  // LDS positions of this thread for stage 0; a stage adds BK * LDT elements (one add per operand and slab)
+  T *swA = sA + row0 * LDT + col0, *swB = sB + row0 * LDT + col0;
   auto sstore = [&](int buf) {
+    T *wa = swA + buf * (BK * LDT), *wb = swB + buf * (BK * LDT);
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
-      int c = tid + h * NTHREADS;
-      int row = c / CPR, col = (c % CPR) * EPV;
-      *reinterpret_cast<vec_t *>(sA + (buf * BK + row) * LDT + col) = ra[h];
-      *reinterpret_cast<vec_t *>(sB + (buf * BK + row) * LDT + col) = rb[h];
+      *reinterpret_cast<vec_t *>(wa + h * RSTEP * LDT) = ra[h];
+      *reinterpret_cast<vec_t *>(wb + h * RSTEP * LDT) = rb[h];
     }
   };
+  const int fk = lane >> 4, fm = lane & 15;
+  const T *pa0 = sA + fk * LDT + wm * 64 + fm, *pb0 = sB + fk * LDT + wn * 64 + fm;   // fragment position, stage 0, ks 0
 
-  gload(0);
+  gload();
   sstore(0);
   __syncthreads();
-  const int fk = lane >> 4, fm = lane & 15;
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nkt) gload(kt + 1);
-    const T *pa = sA + buf * BK * LDT + wm * 64 + fm;
-    const T *pb = sB + buf * BK * LDT + wn * 64 + fm;
+    if (kt + 1 < nkt) gload();
+    const T *pa = pa0 + buf * (BK * LDT), *pb = pb0 + buf * (BK * LDT);
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
       T a[4], b[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        a[t] = pa[(ks * 4 + fk) * LDT + t * 16];
-        b[t] = pb[(ks * 4 + fk) * LDT + t * 16];
+        a[t] = pa[ks * 4 * LDT + t * 16];
+        b[t] = pb[ks * 4 * LDT + t * 16];
         if (NEG) a[t] = -a[t];
       }
 #pragma unroll
@@ -147,8 +162,10 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
 // transposing the tile through LDS in two 64-row halves turns that into 16-byte accesses of full
 // 512-byte rows (8 + 8 per lane for fp32).  `smem` = the mainloop's staging buffer (free after its
 // final barrier; needs 64 x 132 elements).  All 256 threads must call it.
-template <typename T, bool ADD>
+enum { WB_STORE = 0, WB_ADD = 1, WB_SUB = 2, WB_STORE_NEG = 3 };   // C = acc | C += acc | C -= acc | C = -acc
+template <typename T, int MODE>
 __device__ __forceinline__ void tile_writeback(const Acc<T> &acc, T *Cg, int64_t ldc, T *smem) {
+  constexpr bool ADD = MODE == WB_ADD || MODE == WB_SUB;
   using vec_t = typename Traits<T>::vec_t;
   constexpr int EPV = Traits<T>::EPV;
   constexpr int LDW = 132;
@@ -187,7 +204,7 @@ __device__ __forceinline__ void tile_writeback(const Acc<T> &acc, T *Cg, int64_t
       for (int h = 0; h < SUB; ++h) {
         const int c = tid + (h0 + h) * NTHREADS, row = c / CPR, col = (c % CPR) * EPV;
         const vec_t s = *reinterpret_cast<const vec_t *>(smem + row * LDW + col);
-        vec_t o = ADD ? v[h] + s : s;
+        vec_t o = MODE == WB_ADD ? v[h] + s : (MODE == WB_SUB ? v[h] - s : (MODE == WB_STORE_NEG ? -s : s));
         *reinterpret_cast<vec_t *>(Cg + (int64_t)(half * 64 + row) * ldc + col) = o;
       }
     }

@@ -90,10 +90,10 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
   const T *Prow = Al + (int64_t)kr0 * lda;
   Acc<T> acc;
   acc.zero();
-  tile_mainloop<T, true>(acc, Prow + (int64_t)ib * NB, lda, Prow + col0, lda, depth, smem);
+  tile_mainloop<T, false>(acc, Prow + (int64_t)ib * NB, lda, Prow + col0, lda, depth, smem);
   T *C = Al + (int64_t)ib * NB * lda + col0;
-  if (first) tile_writeback<T, false>(acc, C, lda, smem);
-  else tile_writeback<T, true>(acc, C, lda, smem);
+  if (first) tile_writeback<T, WB_STORE_NEG>(acc, C, lda, smem);       // C = -P^T P (first touch of a W tile)
+  else tile_writeback<T, WB_SUB>(acc, C, lda, smem);                   // C -= P^T P
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -54,14 +54,14 @@ __global__ __launch_bounds__(256) void k_v0_rmw_stagger(const float *A, const fl
   Acc<float> acc; acc.zero();
   int bi = blockIdx.y, bj = blockIdx.x;
   tile_mainloop<float, true>(acc, A + bi * 128, M, B + bj * 128, N, K, smem);
-  tile_writeback<float, true>(acc, C + (int64_t)bi * 128 * N + bj * 128, N, smem);
+  tile_writeback<float, WB_ADD>(acc, C + (int64_t)bi * 128 * N + bj * 128, N, smem);
 }
 __global__ __launch_bounds__(256) void k_v0_rmw_wb(const float *A, const float *B, float *C, int M, int N, int K) {
   __shared__ __align__(16) float smem[tile_smem_elems<float>()];
   Acc<float> acc; acc.zero();
   int bi = blockIdx.y, bj = blockIdx.x;
   tile_mainloop<float, true>(acc, A + bi * 128, M, B + bj * 128, N, K, smem);
-  tile_writeback<float, true>(acc, C + (int64_t)bi * 128 * N + bj * 128, N, smem);
+  tile_writeback<float, WB_ADD>(acc, C + (int64_t)bi * 128 * N + bj * 128, N, smem);
 }
 
 // ---------------- V1: 32x32x2 MFMA, register staging, unpadded LDS [BK][128]

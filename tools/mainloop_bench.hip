@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float *A, const float *B, fl
   if (VAR == 0) tile_mainloop<float, false>(acc, A + bi * 128, M, B + bj * 128, N, K, smem);
   else if (VAR == 9) tile_mainloop<float, true>(acc, A + bi * 128, M, B + bj * 128, N, K, smem);
   else mainloop_x<VAR>(acc, A + bi * 128, M, B + bj * 128, N, K, smem);
-  tile_writeback<float, false>(acc, C + (int64_t)bi * 128 * N + bj * 128, N, smem);
+  tile_writeback<float, WB_STORE>(acc, C + (int64_t)bi * 128 * N + bj * 128, N, smem);
 }
 
 template <int VAR> void run(const char *name, const float *A, const float *B, float *C, int M, int N, int K) {
@@ -461,8 +461,9 @@ template <int VAR> void run(const char *name, const float *A, const float *B, fl
   CK(hipMemcpy(h.data(), C + 12345, 16, hipMemcpyDeviceToHost));
   printf("%-28s M=N=%d K=%5d: %7.1f TFLOP/s  (C[12345]=%.4f)\n", name, M, K, 2.0 * M * N * K / (ms / R * 1e-3) / 1e12, h[0]);
 }
-int main() {
+int main(int argc, char **argv) {
   const int M = 8192, N = 8192, Kmax = 8192;
+  const bool only_v0 = argc > 1;        // counter passes: just the product engine at K = 8192
   std::vector<float> ha((size_t)Kmax * M), hb((size_t)Kmax * N);
   const bool gauss = getenv("MB_GAUSS") != nullptr;
   if (gauss) {
@@ -474,6 +475,7 @@ int main() {
   float *A, *B, *C;
   CK(hipMalloc(&A, ha.size() * 4)); CK(hipMalloc(&B, hb.size() * 4)); CK(hipMalloc(&C, (size_t)M * N * 4));
   CK(hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  if (only_v0) { run<0>("v0 product engine", A, B, C, M, N, 8192); return 0; }
   {
     dim3 g(N / 128, M / 128);
     for (int K : {8192, 1024}) {
