@@ -7,6 +7,7 @@
 // without writing it to HBM, re-derives dK/dtheta for the same (i,j) from X staged in LDS and
 // reduces (alpha_i alpha_j - Kinv_ij) * dK_ij to d+2 partial sums.  A second tiny kernel sums the
 // per-tile partials in a fixed order (deterministic, no float atomics).
+#include <stdlib.h>
 #include "api_common.hpp"
 #include "covariance.hpp"
 #include "../../include/plmc.h"
@@ -21,10 +22,13 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_kinv_grad(int k
                                                          const T *__restrict__ X, int n, int d,
                                                          const T *__restrict__ ell, const T *__restrict__ oscale,
                                                          T *Kinv, int64_t ldk, int64_t strideK, T *kinv_diag,
-                                                         double *__restrict__ partials, int nlat) {
+                                                         double *__restrict__ partials, int nlat, int plain) {
   const int m = (int)(n_pad / NB);
   int lat, ib, jb;
-  if (!xcd_tri_decode(blockIdx.x, m, nlat, lat, ib, jb)) return;
+  if (plain) {                         // plain (jb, ib, lat) grid: the default
+    jb = blockIdx.x; ib = blockIdx.y; lat = blockIdx.z;
+    if (jb < ib) return;
+  } else if (!xcd_tri_decode(blockIdx.x, m, nlat, lat, ib, jb)) return;   // dev knob PLMC_KINV_XCD: XCD-dealt 8 x 8 super-tiles
   __shared__ __align__(16) T smem[tile_smem_elems<T>()];
   const T *Wl = W + (int64_t)lat * strideW + (int64_t)jb * NB * ldw;
   Acc<T> acc;
@@ -188,11 +192,14 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
   PLMC_REQUIRE(aligned16(W), "unaligned W");
   hipStream_t st = (hipStream_t)stream;
   const int m = (int)(n_pad / NB);
-  dim3 grid(xcd_tri_grid(m, q)), block(NTHREADS);
+  // tile order: the XCD-dealt super-tile order was ahead with the first tile engine (104 vs 98 TF); with the
+  // engine at 142 TF the plain grid is (109 vs 107 TF at q = 8, 91 vs 88 at q = 1), so it is the default
+  const int plain = getenv("PLMC_KINV_XCD") ? 0 : 1;
+  const dim3 grid = plain ? dim3(m, m, q) : dim3(xcd_tri_grid(m, q)), block(NTHREADS);
   double *part = reinterpret_cast<double *>(partials);
 #define PLMC_LAUNCH_KG(DC)                                                                                          \
   hipLaunchKernelGGL((k_kinv_grad<T, DC>), grid, block, 0, st, kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell,   \
-                     oscale, Kinv, ldk, strideK, kinv_diag, part, q)
+                     oscale, Kinv, ldk, strideK, kinv_diag, part, q, plain)
   {
     const double np = (double)n_pad;
     ProfScope ps(PK_KINV_GRAD, st, q * np * np * np / 3.0, q * (np * np / 2) * sizeof(T));
