@@ -105,18 +105,29 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
   vec_t ra[NCH], rb[NCH];
   const int nkt = K / BK;
   const int row0 = tid / CPR, col0 = (tid % CPR) * EPV;
-  const T *ga = Ag + (int64_t)((REV ? (nkt - 1) * BK : 0) + row0) * lda + col0;
-  const T *gb = Bg + (int64_t)((REV ? (nkt - 1) * BK : 0) + row0) * ldb + col0;
-  const int64_t stepA = (REV ? -(int64_t)BK : (int64_t)BK) * lda, stepB = (REV ? -(int64_t)BK : (int64_t)BK) * ldb;
-  const int64_t rsA = (int64_t)RSTEP * lda, rsB = (int64_t)RSTEP * ldb;
+  // global loads are raw buffer loads: descriptor = wave-uniform slab base (advanced with scalar adds and rebuilt
+  // per slab: a 32-bit soffset would wrap on the 16 GB factor buffers of n = 44 484), voffset = a loop-invariant
+  // byte offset per chunk -- no vector instruction is spent on addresses
+  const char *baseA = reinterpret_cast<const char *>(Ag) + (int64_t)(REV ? (nkt - 1) * BK : 0) * lda * (int64_t)sizeof(T);
+  const char *baseB = reinterpret_cast<const char *>(Bg) + (int64_t)(REV ? (nkt - 1) * BK : 0) * ldb * (int64_t)sizeof(T);
+  const int64_t stepA = (REV ? -(int64_t)BK : (int64_t)BK) * lda * (int64_t)sizeof(T);
+  const int64_t stepB = (REV ? -(int64_t)BK : (int64_t)BK) * ldb * (int64_t)sizeof(T);
+  unsigned offA[NCH], offB[NCH];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) {
+    offA[h] = (unsigned)(((int64_t)(row0 + h * RSTEP) * lda + col0) * (int64_t)sizeof(T));
+    offB[h] = (unsigned)(((int64_t)(row0 + h * RSTEP) * ldb + col0) * (int64_t)sizeof(T));
+  }
   auto gload = [&]() {
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(baseA), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(baseB), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
-      ra[h] = *reinterpret_cast<const vec_t *>(ga + h * rsA);
-      rb[h] = *reinterpret_cast<const vec_t *>(gb + h * rsB);
+      ra[h] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rA, offA[h], 0, 0));
+      rb[h] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rB, offB[h], 0, 0));
     }
-    ga += stepA;
-    gb += stepB;
+    baseA += stepA;
+    baseB += stepB;
   };
   // LDS positions of this thread for stage 0; a stage adds BK * LDT elements (one add per operand and slab)
   T *swA = sA + row0 * LDT + col0, *swB = sB + row0 * LDT + col0;
