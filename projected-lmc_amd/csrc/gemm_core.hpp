@@ -5,7 +5,7 @@
 // HBM layout was chosen for: Khat = U^T U with U upper / row-major makes the Cholesky trailing
 // update, the panel solve, the forward substitution W = U^-T and K^-1 = W^T W all TN products,
 // so tiles stream from global to LDS without a transpose and MFMA fragments are read
-// conflict-free (LDS row stride 144 == 16 mod 32 words).
+// conflict-free (LDS row order / stride: see tile_mainloop).
 //
 // Workgroup = 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 =
 // 4 x 4 MFMA tiles of v_mfma_{f32,f64}_16x16x4 (the f32 form runs at the f32 matrix peak,
@@ -19,7 +19,7 @@ namespace plmc {
 
 constexpr int NB = 128;    // block edge of all blocked algorithms == tile edge
 constexpr int BK = 16;     // k-depth of one LDS stage
-constexpr int LDT = 144;   // LDS row stride in elements
+constexpr int LDT = 132;   // LDS row stride in elements (see tile_mainloop for the row order)
 constexpr int NTHREADS = 256;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -64,8 +64,9 @@ template <typename T> struct Acc {
 // 128 accumulator registers; without a floor hipcc spends 230+ more and leaves one wave per SIMD.
 template <typename T> constexpr int TILE_MIN_WAVES = sizeof(T) == 8 ? 2 : 1;
 
-// LDS needed by tile_mainloop: 2 stages x (A,B) x BK x LDT elements.
-template <typename T> constexpr int tile_smem_elems() { return 2 * 2 * BK * LDT; }
+// LDS owned by a tile kernel: at least the 2 stages x (A,B) x BK x LDT elements of tile_mainloop.
+// (kept at the 144-stride size: the epilogues of the gradient kernels stage up to 2 x 128 x 33 + 256 elements in it)
+template <typename T> constexpr int tile_smem_elems() { return 2 * 2 * BK * 144; }
 
 // Position of accumulator element (mt, nt, r) of this lane inside the 128x128 block tile.
 template <typename T> __device__ __forceinline__ int tile_row(int wm, int mt, int lane, int r) {
@@ -129,18 +130,23 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
     baseA += stepA;
     baseB += stepB;
   };
-  // LDS positions of this thread for stage 0; a stage adds BK * LDT elements (one add per operand and slab)
-  T *swA = sA + row0 * LDT + col0, *swB = sB + row0 * LDT + col0;
+  // LDS layout of a slab: contraction row r = 4 ks + fk (MFMA step ks, lane group fk) is stored as LDS row
+  // 4 fk + ks, stride LDT = 132.  A lane's fragments of steps ks and ks + 1 are then 132 elements apart and, with the
+  // 16-element tile offsets, within the 8-bit offset range of ds_read2 from ONE base register (two bases per
+  // operand and slab instead of a new one per step); lane groups sit 4 * 132 = 16 (mod 32) words apart, so the two
+  // half-waves of a read still cover all banks.  A stage adds BK * LDT elements (one add per operand and slab).
+  T *swA = sA + col0, *swB = sB + col0;
   auto sstore = [&](int buf) {
     T *wa = swA + buf * (BK * LDT), *wb = swB + buf * (BK * LDT);
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
-      *reinterpret_cast<vec_t *>(wa + h * RSTEP * LDT) = ra[h];
-      *reinterpret_cast<vec_t *>(wb + h * RSTEP * LDT) = rb[h];
+      const int r = row0 + h * RSTEP, rp = (r & 3) * 4 + (r >> 2);
+      *reinterpret_cast<vec_t *>(wa + rp * LDT) = ra[h];
+      *reinterpret_cast<vec_t *>(wb + rp * LDT) = rb[h];
     }
   };
   const int fk = lane >> 4, fm = lane & 15;
-  const T *pa0 = sA + fk * LDT + wm * 64 + fm, *pb0 = sB + fk * LDT + wn * 64 + fm;   // fragment position, stage 0, ks 0
+  const T *pa0 = sA + fk * 4 * LDT + wm * 64 + fm, *pb0 = sB + fk * 4 * LDT + wn * 64 + fm;   // stage 0, step 0
 
   gload();
   sstore(0);
@@ -154,8 +160,8 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
       T a[4], b[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        a[t] = pa[ks * 4 * LDT + t * 16];
-        b[t] = pb[ks * 4 * LDT + t * 16];
+        a[t] = pa[ks * LDT + t * 16];
+        b[t] = pb[ks * LDT + t * 16];
         if (NEG) a[t] = -a[t];
       }
 #pragma unroll
