@@ -179,17 +179,38 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
 // transposing the tile through LDS in two 64-row halves turns that into 16-byte accesses of full
 // 512-byte rows (8 + 8 per lane for fp32).  `smem` = the mainloop's staging buffer (free after its
 // final barrier; needs 64 x 132 elements).  All 256 threads must call it.
+// The C tile is read with raw buffer loads (descriptor on the tile, per-thread voffset fixed, row-chunk offset in
+// soffset: no vector instruction for addresses) in chunks of 2 x 16 bytes per thread, software-pipelined: the
+// first chunk is requested before the accumulators are staged, every later one of a half while the previous is
+// combined and stored -- an un-prefetched read-modify-write left the workgroup idle for two HBM round trips per
+// tile, ~10 % of a depth-1024 update tile.  (Requesting the second half's first chunk across the half boundary as
+// well produced wrong factors under the look-ahead at n = 8192, q = 8 and correct ones with PLMC_SERIAL=1; not
+// understood, so each half starts its own pipeline after its staging barrier.)
 enum { WB_STORE = 0, WB_ADD = 1, WB_SUB = 2, WB_STORE_NEG = 3 };   // C = acc | C += acc | C -= acc | C = -acc
 template <typename T, int MODE>
 __device__ __forceinline__ void tile_writeback(const Acc<T> &acc, T *Cg, int64_t ldc, T *smem) {
   constexpr bool ADD = MODE == WB_ADD || MODE == WB_SUB;
   using vec_t = typename Traits<T>::vec_t;
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
   constexpr int EPV = Traits<T>::EPV;
   constexpr int LDW = 132;
   constexpr int CPR = 128 / EPV;                       // 16-byte chunks per row
   constexpr int NCH = 64 * CPR / NTHREADS;             // chunks per thread per half (8 fp32 / 16 fp64)
+  constexpr int RSTEP = NTHREADS / CPR;                // rows between a thread's chunks (8 / 4)
+  constexpr int CH = 2;                                // chunks per pipeline stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  const int row0 = tid / CPR, col0 = (tid % CPR) * EPV;
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(Cg, 0, 0x7fffffff, 0x00020000);
+  const unsigned voff = (unsigned)(((int64_t)row0 * ldc + col0) * (int64_t)sizeof(T));
+  const unsigned rstep = (unsigned)((int64_t)RSTEP * ldc * (int64_t)sizeof(T));      // wave-uniform
+  auto cload = [&](int half, int h0, vec_t (&v)[CH]) {
+#pragma unroll
+    for (int h = 0; h < CH; ++h)
+      v[h] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rC, voff, (unsigned)(half * (64 / RSTEP) + h0 + h) * rstep, 0));
+  };
+  vec_t vcur[CH], vnext[CH];
+  if (ADD) cload(0, 0, vcur);
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     if (half) __syncthreads();                         // previous half fully read back
@@ -204,26 +225,21 @@ __device__ __forceinline__ void tile_writeback(const Acc<T> &acc, T *Cg, int64_t
         }
     }
     __syncthreads();
-    // chunks are moved SUB at a time: all 16 fp64 chunks in flight at once cost 64 more registers than the
-    // main loop needs and halved the occupancy of every fp64 tile kernel
-    constexpr int SUB = sizeof(T) == 8 ? 4 : NCH;
+    if (ADD && half == 1) cload(1, 0, vcur);
 #pragma unroll
-    for (int h0 = 0; h0 < NCH; h0 += SUB) {
-      vec_t v[SUB];
+    for (int h0 = 0; h0 < NCH; h0 += CH) {
       if (ADD) {
-#pragma unroll
-        for (int h = 0; h < SUB; ++h) {
-          const int c = tid + (h0 + h) * NTHREADS, row = c / CPR, col = (c % CPR) * EPV;
-          v[h] = *reinterpret_cast<const vec_t *>(Cg + (int64_t)(half * 64 + row) * ldc + col);
-        }
+        if (h0 + CH < NCH) cload(half, h0 + CH, vnext);
       }
 #pragma unroll
-      for (int h = 0; h < SUB; ++h) {
-        const int c = tid + (h0 + h) * NTHREADS, row = c / CPR, col = (c % CPR) * EPV;
-        const vec_t s = *reinterpret_cast<const vec_t *>(smem + row * LDW + col);
-        vec_t o = MODE == WB_ADD ? v[h] + s : (MODE == WB_SUB ? v[h] - s : (MODE == WB_STORE_NEG ? -s : s));
-        *reinterpret_cast<vec_t *>(Cg + (int64_t)(half * 64 + row) * ldc + col) = o;
+      for (int h = 0; h < CH; ++h) {
+        const vec_t sv = *reinterpret_cast<const vec_t *>(smem + (row0 + (h0 + h) * RSTEP) * LDW + col0);
+        const vec_t o = MODE == WB_ADD ? vcur[h] + sv : (MODE == WB_SUB ? vcur[h] - sv : (MODE == WB_STORE_NEG ? -sv : sv));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o), rC, voff,
+                                               (unsigned)(half * (64 / RSTEP) + h0 + h) * rstep, 0);
       }
+#pragma unroll
+      for (int h = 0; h < CH; ++h) vcur[h] = vnext[h];
     }
   }
 }
