@@ -21,6 +21,9 @@ constexpr int NB = 128;    // block edge of all blocked algorithms == tile edge
 constexpr int BK = 16;     // k-depth of one LDS stage
 constexpr int LDT = 132;   // LDS row stride in elements (see tile_mainloop for the row order)
 constexpr int NTHREADS = 256;
+// start of the B stages inside the staging buffer: the A stages (2 * BK * LDT = 4224 elements) rounded up to a
+// multiple of 256 elements, which keeps the B fragments of two steps within one ds_read2 offset window
+constexpr int SB_OFF = 4352;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -101,7 +104,7 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   T *sA = smem;
-  T *sB = smem + 2 * BK * LDT;
+  T *sB = smem + SB_OFF;
 
   vec_t ra[NCH], rb[NCH];
   const int nkt = K / BK;
@@ -135,14 +138,15 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
   // 16-element tile offsets, within the 8-bit offset range of ds_read2 from ONE base register (two bases per
   // operand and slab instead of a new one per step); lane groups sit 4 * 132 = 16 (mod 32) words apart, so the two
   // half-waves of a read still cover all banks.  A stage adds BK * LDT elements (one add per operand and slab).
-  T *swA = sA + col0, *swB = sB + col0;
+  // a thread's rows row0 + h * RSTEP land on LDS rows rp0 + h * RSTEP / 4 (RSTEP is a multiple of 4): one base
+  const int rp0 = (row0 & 3) * 4 + (row0 >> 2);
+  T *swA = sA + rp0 * LDT + col0;
   auto sstore = [&](int buf) {
-    T *wa = swA + buf * (BK * LDT), *wb = swB + buf * (BK * LDT);
+    T *wa = swA + buf * (BK * LDT);
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
-      const int r = row0 + h * RSTEP, rp = (r & 3) * 4 + (r >> 2);
-      *reinterpret_cast<vec_t *>(wa + rp * LDT) = ra[h];
-      *reinterpret_cast<vec_t *>(wb + rp * LDT) = rb[h];
+      *reinterpret_cast<vec_t *>(wa + h * (RSTEP / 4) * LDT) = ra[h];
+      *reinterpret_cast<vec_t *>(wa + SB_OFF + h * (RSTEP / 4) * LDT) = rb[h];
     }
   };
   const int fk = lane >> 4, fm = lane & 15;
