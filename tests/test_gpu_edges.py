@@ -177,3 +177,24 @@ def test_sarcos_scale_single_latent_fp32(eng):
     assert torch.allclose(lp_half - lp.detach(), 0.375 * quad, rtol=1e-4)
     eng.free_workspaces()
     torch.cuda.empty_cache()
+
+
+def test_sweep_is_deterministic_at_metric_shape(eng):
+    """The look-ahead runs the chain, the head and the tail updates of the sweep on different streams; every tile
+    still receives its updates in a fixed order, so repeated factorisations at the metric shape must agree bit for
+    bit (a race between the streams would show up here as a difference or as a non-PD report)."""
+    n, d, q = 8192, 8, 8
+    g = torch.Generator().manual_seed(5)
+    X = (2 * torch.rand(n, d, generator=g) - 1).to(DEV)
+    y = torch.randn(q, n, generator=g).to(DEV)
+    ell = torch.linspace(0.4, 1.0, q)[:, None].expand(q, d).contiguous().to(DEV)
+    noise = torch.linspace(0.05, 0.5, q).to(DEV)
+    outs = []
+    for _ in range(4):
+        yg, eg = y.clone().requires_grad_(), ell.clone().requires_grad_()
+        lp = eng.exact_latent_log_prob("matern52", X, eg, None, noise, yg)
+        lp.sum().backward()
+        outs.append((lp.detach().clone(), yg.grad.clone(), eg.grad.clone()))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+    assert bool(torch.isfinite(outs[0][0]).all())
