@@ -254,7 +254,7 @@ def main():
             # the process: they come from the committed rocprofv3 --pmc passes of this same command)
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                kname = {"k_trail": "k_update<float, 0>", "k_trail_head": "k_update<float, 2>", "k_kinv_grad": "k_kinv_grad<float, 8>"}.get(dom, dom + "<float>")
+                kname = {"k_trail": "k_update<float, 0, 4>", "k_trail_head": "k_update<float, 2, 4>", "k_kinv_grad": "k_kinv_grad<float, 8>"}.get(dom, dom + "<float>")
                 if world == 1 and kname in pmc["kernels"]:
                     res["roofline"]["traffic"] = pmc["kernels"][kname]["hbm_bytes_corrected"]
                     res["roofline"]["traffic_note"] = ("bytes/launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/"

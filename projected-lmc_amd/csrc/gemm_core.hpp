@@ -51,11 +51,13 @@ template <> struct Traits<double> {
   static __device__ __forceinline__ int acc_row(int lane, int r) { return (lane >> 4) + (r << 2); }
 };
 
-template <typename T> struct Acc {
-  typename Traits<T>::acc_t v[4][4];
+// Accumulators of one wave: MT x 4 MFMA tiles.  MT = 4: the 128 x 128 block tile (64 x 64 per wave); MT = 2: a
+// 64-row x 128-column half tile (32 x 64 per wave) for launches that would not fill the CUs with full tiles.
+template <typename T, int MT = 4> struct Acc {
+  typename Traits<T>::acc_t v[MT][4];
   __device__ __forceinline__ void zero() {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -72,8 +74,8 @@ template <typename T> constexpr int TILE_MIN_WAVES = sizeof(T) == 8 ? 2 : 1;
 template <typename T> constexpr int tile_smem_elems() { return 2 * 2 * BK * 144; }
 
 // Position of accumulator element (mt, nt, r) of this lane inside the 128x128 block tile.
-template <typename T> __device__ __forceinline__ int tile_row(int wm, int mt, int lane, int r) {
-  return wm * 64 + mt * 16 + Traits<T>::acc_row(lane, r);
+template <typename T, int MT = 4> __device__ __forceinline__ int tile_row(int wm, int mt, int lane, int r) {
+  return wm * (16 * MT) + mt * 16 + Traits<T>::acc_row(lane, r);
 }
 __device__ __forceinline__ int tile_col(int wn, int nt, int lane) { return wn * 64 + nt * 16 + (lane & 15); }
 
@@ -90,15 +92,19 @@ __device__ __forceinline__ int tile_col(int wn, int nt, int lane) { return wn * 
 // advance by pointer increments, LDS positions are loop-invariant registers plus one stage offset per slab, and the
 // sign of C -= A^T B is applied in the epilogue.  (Unrolling the slab loop by two to make the stage a compile-time
 // constant cost 50 more registers and an occupancy step: 128 TF.)
-template <typename T, bool NEG, bool REV = false>
-__device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__ Ag, int64_t lda,
+template <typename T, bool NEG, bool REV = false, int MT = 4>
+__device__ __forceinline__ void tile_mainloop(Acc<T, MT> &acc, const T *__restrict__ Ag, int64_t lda,
                                               const T *__restrict__ Bg, int64_t ldb, int K, T *smem) {
   using Tr = Traits<T>;
   using vec_t = typename Tr::vec_t;
   constexpr int EPV = Tr::EPV;
-  constexpr int CPR = 128 / EPV;                     // 16-byte chunks per tile row
-  constexpr int NCH = BK * CPR / NTHREADS;           // chunks per thread per operand (2 / 4)
-  constexpr int RSTEP = NTHREADS / CPR;              // rows between a thread's chunks (8 / 4)
+  // B slab: BK rows x 128 columns; A slab: BK rows x AW = 32 MT columns (the tile's rows)
+  constexpr int AW = 32 * MT;
+  constexpr int CPR = 128 / EPV, CPRA = AW / EPV;    // 16-byte chunks per slab row
+  constexpr int NCH = BK * CPR / NTHREADS;           // chunks per thread, B (2 / 4)
+  constexpr int NCHA = BK * CPRA / NTHREADS;         // chunks per thread, A (MT = 4: as B; MT = 2: 1 / 2)
+  constexpr int RSTEP = NTHREADS / CPR, RSTEPA = NTHREADS / CPRA;   // rows between a thread's chunks
+  static_assert(NCHA >= 1 && RSTEP % 4 == 0 && RSTEPA % 4 == 0, "slab split");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -106,9 +112,10 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
   T *sA = smem;
   T *sB = smem + SB_OFF;
 
-  vec_t ra[NCH], rb[NCH];
+  vec_t ra[NCHA], rb[NCH];
   const int nkt = K / BK;
   const int row0 = tid / CPR, col0 = (tid % CPR) * EPV;
+  const int row0a = tid / CPRA, col0a = (tid % CPRA) * EPV;
   // global loads are raw buffer loads: descriptor = wave-uniform slab base (advanced with scalar adds and rebuilt
   // per slab: a 32-bit soffset would wrap on the 16 GB factor buffers of n = 44 484), voffset = a loop-invariant
   // byte offset per chunk -- no vector instruction is spent on addresses
@@ -116,20 +123,18 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
   const char *baseB = reinterpret_cast<const char *>(Bg) + (int64_t)(REV ? (nkt - 1) * BK : 0) * ldb * (int64_t)sizeof(T);
   const int64_t stepA = (REV ? -(int64_t)BK : (int64_t)BK) * lda * (int64_t)sizeof(T);
   const int64_t stepB = (REV ? -(int64_t)BK : (int64_t)BK) * ldb * (int64_t)sizeof(T);
-  unsigned offA[NCH], offB[NCH];
+  unsigned offA[NCHA], offB[NCH];
 #pragma unroll
-  for (int h = 0; h < NCH; ++h) {
-    offA[h] = (unsigned)(((int64_t)(row0 + h * RSTEP) * lda + col0) * (int64_t)sizeof(T));
-    offB[h] = (unsigned)(((int64_t)(row0 + h * RSTEP) * ldb + col0) * (int64_t)sizeof(T));
-  }
+  for (int h = 0; h < NCHA; ++h) offA[h] = (unsigned)(((int64_t)(row0a + h * RSTEPA) * lda + col0a) * (int64_t)sizeof(T));
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) offB[h] = (unsigned)(((int64_t)(row0 + h * RSTEP) * ldb + col0) * (int64_t)sizeof(T));
   auto gload = [&]() {
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(baseA), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(baseB), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int h = 0; h < NCH; ++h) {
-      ra[h] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rA, offA[h], 0, 0));
-      rb[h] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rB, offB[h], 0, 0));
-    }
+    for (int h = 0; h < NCHA; ++h) ra[h] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rA, offA[h], 0, 0));
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) rb[h] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rB, offB[h], 0, 0));
     baseA += stepA;
     baseB += stepB;
   };
@@ -139,18 +144,17 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
   // operand and slab instead of a new one per step); lane groups sit 4 * 132 = 16 (mod 32) words apart, so the two
   // half-waves of a read still cover all banks.  A stage adds BK * LDT elements (one add per operand and slab).
   // a thread's rows row0 + h * RSTEP land on LDS rows rp0 + h * RSTEP / 4 (RSTEP is a multiple of 4): one base
-  const int rp0 = (row0 & 3) * 4 + (row0 >> 2);
-  T *swA = sA + rp0 * LDT + col0;
+  const int rp0 = (row0 & 3) * 4 + (row0 >> 2), rp0a = (row0a & 3) * 4 + (row0a >> 2);
+  T *swB = sB + rp0 * LDT + col0, *swA = sA + rp0a * LDT + col0a;
   auto sstore = [&](int buf) {
-    T *wa = swA + buf * (BK * LDT);
+    T *wa = swA + buf * (BK * LDT), *wb = swB + buf * (BK * LDT);
 #pragma unroll
-    for (int h = 0; h < NCH; ++h) {
-      *reinterpret_cast<vec_t *>(wa + h * (RSTEP / 4) * LDT) = ra[h];
-      *reinterpret_cast<vec_t *>(wa + SB_OFF + h * (RSTEP / 4) * LDT) = rb[h];
-    }
+    for (int h = 0; h < NCHA; ++h) *reinterpret_cast<vec_t *>(wa + h * (RSTEPA / 4) * LDT) = ra[h];
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) *reinterpret_cast<vec_t *>(wb + h * (RSTEP / 4) * LDT) = rb[h];
   };
   const int fk = lane >> 4, fm = lane & 15;
-  const T *pa0 = sA + fk * 4 * LDT + wm * 64 + fm, *pb0 = sB + fk * 4 * LDT + wn * 64 + fm;   // stage 0, step 0
+  const T *pa0 = sA + fk * 4 * LDT + wm * (16 * MT) + fm, *pb0 = sB + fk * 4 * LDT + wn * 64 + fm;   // stage 0, step 0
 
   gload();
   sstore(0);
@@ -161,15 +165,16 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
     const T *pa = pa0 + buf * (BK * LDT), *pb = pb0 + buf * (BK * LDT);
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
-      T a[4], b[4];
+      T a[MT], b[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < MT; ++t) {
         a[t] = pa[ks * LDT + t * 16];
-        b[t] = pb[ks * LDT + t * 16];
         if (NEG) a[t] = -a[t];
       }
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+      for (int t = 0; t < 4; ++t) b[t] = pb[ks * LDT + t * 16];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc.v[mt][nt] = Tr::mfma(a[mt], b[nt], acc.v[mt][nt]);
     }
@@ -191,8 +196,8 @@ __device__ __forceinline__ void tile_mainloop(Acc<T> &acc, const T *__restrict__
 // well produced wrong factors under the look-ahead at n = 8192, q = 8 and correct ones with PLMC_SERIAL=1; not
 // understood, so each half starts its own pipeline after its staging barrier.)
 enum { WB_STORE = 0, WB_ADD = 1, WB_SUB = 2, WB_STORE_NEG = 3 };   // C = acc | C += acc | C -= acc | C = -acc
-template <typename T, int MODE>
-__device__ __forceinline__ void tile_writeback(const Acc<T> &acc, T *Cg, int64_t ldc, T *smem) {
+template <typename T, int MODE, int MT = 4>
+__device__ __forceinline__ void tile_writeback(const Acc<T, MT> &acc, T *Cg, int64_t ldc, T *smem) {
   constexpr bool ADD = MODE == WB_ADD || MODE == WB_SUB;
   using vec_t = typename Traits<T>::vec_t;
   typedef int i32x4_t __attribute__((ext_vector_type(4)));
@@ -215,15 +220,16 @@ __device__ __forceinline__ void tile_writeback(const Acc<T> &acc, T *Cg, int64_t
   };
   vec_t vcur[CH], vnext[CH];
   if (ADD) cload(0, 0, vcur);
+  // MT = 4: two passes of 64 rows, pass h staged by the wave row wm == h; MT = 2: one pass, both wave rows stage
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < MT / 2; ++half) {
     if (half) __syncthreads();                         // previous half fully read back
-    if (wm == half) {
+    if (MT == 2 || wm == half) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = mt * 16 + Traits<T>::acc_row(lane, r);
+          const int row = (MT == 2 ? wm * 32 : 0) + mt * 16 + Traits<T>::acc_row(lane, r);
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) smem[row * LDW + wn * 64 + nt * 16 + (lane & 15)] = acc.v[mt][nt][r];
         }
@@ -276,15 +282,15 @@ __device__ __forceinline__ bool xcd_tri_decode(int w, int m, int nlat, int &lat,
 }
 
 // C[tile] = acc (plain store of the 128x128 tile at Cg, leading dimension ldc).
-template <typename T>
-__device__ __forceinline__ void tile_store(const Acc<T> &acc, T *Cg, int64_t ldc) {
+template <typename T, int MT = 4>
+__device__ __forceinline__ void tile_store(const Acc<T, MT> &acc, T *Cg, int64_t ldc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int row = tile_row<T>(wm, mt, lane, r);
+      int row = tile_row<T, MT>(wm, mt, lane, r);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) Cg[(int64_t)row * ldc + tile_col(wn, nt, lane)] = acc.v[mt][nt][r];
     }

@@ -61,14 +61,19 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_panel(T *A, int
 // ROLE 0 = the big trailing ("tail") update, 1 = the single-row launches inside a group (latency-critical:
 // raised wave priority), 2 = the "head" rows the next group needs.  Separate symbols keep the three launch
 // shapes apart in kernel traces and counter passes.
-template <typename T, int ROLE>
+// MT = 2 splits every 128 x 128 tile into two 64-row halves (grid.y doubled): twice the workgroups for the chain's
+// launches when full tiles would not fill the CUs (single-latent shards).  (k_panel cannot be split this way: it
+// works in place and every output row needs all 128 input rows of its column.)
+template <typename T, int ROLE, int MT = 4>
 __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, int64_t lda, int64_t strideA, int ib0, int r_lo, int r_hi,
                                                       ColMap cm) {
   if (ROLE == 1) __builtin_amdgcn_s_setprio(3);
   // plain row-major tile order: an XCD-dealt super-block order (as k_kinv_grad uses) was 3 % faster for a
   // launch that has the GPU to itself and 25 % slower in the sweep, where launches from three streams
   // interleave and "workgroup w lands on XCD w % 8" no longer holds
-  const int bx = blockIdx.x, ib = ib0 + blockIdx.y, lat = blockIdx.z;
+  constexpr int SPLIT = 4 / MT;                                      // half tiles per tile
+  const int bx = blockIdx.x, ib = ib0 + (int)blockIdx.y / SPLIT, lat = blockIdx.z;
+  const int h0 = ((int)blockIdx.y % SPLIT) * (32 * MT);             // first row of this half inside the block row
   int64_t col0;
   int kr0 = r_lo * NB, depth = (r_hi - r_lo + 1) * NB;
   bool first = false;
@@ -88,12 +93,12 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
   __shared__ __align__(16) T smem[tile_smem_elems<T>()];
   T *Al = A + (int64_t)lat * strideA;
   const T *Prow = Al + (int64_t)kr0 * lda;
-  Acc<T> acc;
+  Acc<T, MT> acc;
   acc.zero();
-  tile_mainloop<T, false>(acc, Prow + (int64_t)ib * NB, lda, Prow + col0, lda, depth, smem);
-  T *C = Al + (int64_t)ib * NB * lda + col0;
-  if (first) tile_writeback<T, WB_STORE_NEG>(acc, C, lda, smem);       // C = -P^T P (first touch of a W tile)
-  else tile_writeback<T, WB_SUB>(acc, C, lda, smem);                   // C -= P^T P
+  tile_mainloop<T, false, false, MT>(acc, Prow + (int64_t)ib * NB + h0, lda, Prow + col0, lda, depth, smem);
+  T *C = Al + ((int64_t)ib * NB + h0) * lda + col0;
+  if (first) tile_writeback<T, WB_STORE_NEG, MT>(acc, C, lda, smem);   // C = -P^T P (first touch of a W tile)
+  else tile_writeback<T, WB_SUB, MT>(acc, C, lda, smem);               // C -= P^T P
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -213,10 +218,21 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     const int nfirst = with_inverse ? r_hi - r_lo + 1 : 0;                       // first-touch W columns: no read
     const double bytes = (2.0 * (tilesU + tilesA + nr * cm.nW) - nr * nfirst) * nb * nb * esz;
     ProfScope ps(cls, st, q * (flopsU + flopsR), q * bytes);
-    const dim3 grid(cm.nU + cm.Taug + cm.nW, nrows, q);
-    if (cls == PK_TRAIL_ROW) hipLaunchKernelGGL((k_update<T, 1>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
-    else if (cls == PK_TRAIL_HEAD) hipLaunchKernelGGL((k_update<T, 2>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
-    else hipLaunchKernelGGL((k_update<T, 0>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
+    const int Cn = cm.nU + cm.Taug + cm.nW;
+    // chain launches with few tiles (single-latent shards) run on 64-row half tiles: twice the workgroups
+    const char *henv = getenv("PLMC_HALF_TILES");          // dev knob: 0 = never, 1 = always, N > 1 = tile-count threshold
+    const double hthr = henv ? (atoi(henv) == 1 ? 1e30 : (double)atoi(henv)) : 640.0;
+    const bool half = cls != PK_TRAIL && (double)Cn * nrows * q <= hthr;
+    const dim3 grid(Cn, half ? 2 * nrows : nrows, q);
+    if (cls == PK_TRAIL_ROW) {
+      if (half) hipLaunchKernelGGL((k_update<T, 1, 2>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
+      else hipLaunchKernelGGL((k_update<T, 1, 4>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
+    } else if (cls == PK_TRAIL_HEAD) {
+      if (half) hipLaunchKernelGGL((k_update<T, 2, 2>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
+      else hipLaunchKernelGGL((k_update<T, 2, 4>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
+    } else {
+      hipLaunchKernelGGL((k_update<T, 0, 4>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
+    }
   };
 
   // whole-sweep bracket on the caller's stream (the per-kernel records of overlapped kernels add up to
