@@ -125,17 +125,19 @@ __global__ __launch_bounds__(NTHREADS) void k_extract_col(const T *__restrict__ 
   if (threadIdx.x == 0) quad[lat] = red[0];
 }
 
-// alpha[i] = sum_{l >= block(i)} W[l][i] z[l].  grid (n_pad / 128, q): one workgroup per block column;
-// 8 row groups x 32 lanes x 16-byte loads (one full 512-byte row segment per row group and step,
-// 4 rows in flight per thread).  HBM-bound: reads the lower triangle of W once.
+// alpha[i] = sum_{l >= block(i)} W[l][i] z[l].  grid (n_pad / 128, q): one workgroup of 1024 threads per block column;
+// 32 row groups (16 fp64) x 32 lanes x 16-byte loads (one full 512-byte row segment per row group and step,
+// 4 rows in flight per thread).  HBM-bound: reads the lower triangle of W once.  With 256 threads a workgroup
+// kept too few bytes in flight, and a single-latent shard has only n_pad / 128 workgroups (0.5 TB/s).
+constexpr int WTMV_NT = 1024;
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_wt_matvec(const T *__restrict__ W, int64_t n_pad, int64_t ldw,
-                                                         int64_t strideW, const T *__restrict__ z,
-                                                         T *__restrict__ alpha) {
+__global__ __launch_bounds__(WTMV_NT) void k_wt_matvec(const T *__restrict__ W, int64_t n_pad, int64_t ldw,
+                                                       int64_t strideW, const T *__restrict__ z,
+                                                       T *__restrict__ alpha) {
   using vec_t = typename Traits<T>::vec_t;
   constexpr int EPV = Traits<T>::EPV;
   constexpr int LPR = 128 / EPV;                 // lanes per row segment (32 fp32 / 64 fp64)
-  constexpr int NRG = NTHREADS / LPR;            // row groups (8 / 4)
+  constexpr int NRG = WTMV_NT / LPR;             // row groups (32 / 16)
   __shared__ double red[NRG][NB];
   const int lat = blockIdx.y;
   const int cl = (threadIdx.x % LPR) * EPV, rg = threadIdx.x / LPR;
@@ -355,7 +357,7 @@ int wt_matvec_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, cons
   PLMC_REQUIRE(W && z && alpha, "null pointer");
   PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0, "n_pad must be a multiple of NB");
   ProfScope ps(PK_WTMV, (hipStream_t)stream, q * (double)n_pad * n_pad, q * ((double)n_pad * n_pad / 2) * sizeof(T));
-  hipLaunchKernelGGL(k_wt_matvec<T>, dim3((unsigned)(n_pad / NB), q), dim3(NTHREADS), 0, (hipStream_t)stream, W,
+  hipLaunchKernelGGL(k_wt_matvec<T>, dim3((unsigned)(n_pad / NB), q), dim3(WTMV_NT), 0, (hipStream_t)stream, W,
                      n_pad, ldw, strideW, z, alpha);
   return launch_status(__func__);
 }
