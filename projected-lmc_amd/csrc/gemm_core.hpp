@@ -52,14 +52,15 @@ template <> struct Traits<double> {
 };
 
 // Accumulators of one wave: MT x 4 MFMA tiles.  MT = 4: the 128 x 128 block tile (64 x 64 per wave); MT = 2: a
-// 64-row x 128-column half tile (32 x 64 per wave) for launches that would not fill the CUs with full tiles.
-template <typename T, int MT = 4> struct Acc {
-  typename Traits<T>::acc_t v[MT][4];
+// 64-row x 128-column half tile (32 x 64 per wave) for launches that would not fill the CUs with full tiles;
+// NT = 2: a 128-row x 64-column half tile (64 x 32 per wave), for the in-place row panel.
+template <typename T, int MT = 4, int NT = 4> struct Acc {
+  typename Traits<T>::acc_t v[MT][NT];
   __device__ __forceinline__ void zero() {
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < NT; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[a][b][r] = T(0);
   }
@@ -77,7 +78,7 @@ template <typename T> constexpr int tile_smem_elems() { return 2 * 2 * BK * 144;
 template <typename T, int MT = 4> __device__ __forceinline__ int tile_row(int wm, int mt, int lane, int r) {
   return wm * (16 * MT) + mt * 16 + Traits<T>::acc_row(lane, r);
 }
-__device__ __forceinline__ int tile_col(int wn, int nt, int lane) { return wn * 64 + nt * 16 + (lane & 15); }
+template <int NT = 4> __device__ __forceinline__ int tile_col(int wn, int nt, int lane) { return wn * (16 * NT) + nt * 16 + (lane & 15); }
 
 // acc += sum_{k < K} Ag[k][0..127]^T * Bg[k][0..127]      (NEG: the A fragments are negated -- dev benches only;
 // the product kernels subtract in the epilogue instead, tile_writeback<.., WB_SUB>)
@@ -92,19 +93,19 @@ __device__ __forceinline__ int tile_col(int wn, int nt, int lane) { return wn * 
 // advance by pointer increments, LDS positions are loop-invariant registers plus one stage offset per slab, and the
 // sign of C -= A^T B is applied in the epilogue.  (Unrolling the slab loop by two to make the stage a compile-time
 // constant cost 50 more registers and an occupancy step: 128 TF.)
-template <typename T, bool NEG, bool REV = false, int MT = 4>
-__device__ __forceinline__ void tile_mainloop(Acc<T, MT> &acc, const T *__restrict__ Ag, int64_t lda,
+template <typename T, bool NEG, bool REV = false, int MT = 4, int NT = 4>
+__device__ __forceinline__ void tile_mainloop(Acc<T, MT, NT> &acc, const T *__restrict__ Ag, int64_t lda,
                                               const T *__restrict__ Bg, int64_t ldb, int K, T *smem) {
   using Tr = Traits<T>;
   using vec_t = typename Tr::vec_t;
   constexpr int EPV = Tr::EPV;
-  // B slab: BK rows x 128 columns; A slab: BK rows x AW = 32 MT columns (the tile's rows)
-  constexpr int AW = 32 * MT;
-  constexpr int CPR = 128 / EPV, CPRA = AW / EPV;    // 16-byte chunks per slab row
+  // B slab: BK rows x BW = 32 NT columns (the tile's columns); A slab: BK rows x AW = 32 MT columns (the tile's rows)
+  constexpr int AW = 32 * MT, BW = 32 * NT;
+  constexpr int CPR = BW / EPV, CPRA = AW / EPV;     // 16-byte chunks per slab row
   constexpr int NCH = BK * CPR / NTHREADS;           // chunks per thread, B (2 / 4)
   constexpr int NCHA = BK * CPRA / NTHREADS;         // chunks per thread, A (MT = 4: as B; MT = 2: 1 / 2)
   constexpr int RSTEP = NTHREADS / CPR, RSTEPA = NTHREADS / CPRA;   // rows between a thread's chunks
-  static_assert(NCHA >= 1 && RSTEP % 4 == 0 && RSTEPA % 4 == 0, "slab split");
+  static_assert(NCHA >= 1 && NCH >= 1 && RSTEP % 4 == 0 && RSTEPA % 4 == 0, "slab split");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -154,7 +155,7 @@ __device__ __forceinline__ void tile_mainloop(Acc<T, MT> &acc, const T *__restri
     for (int h = 0; h < NCH; ++h) *reinterpret_cast<vec_t *>(wb + h * (RSTEP / 4) * LDT) = rb[h];
   };
   const int fk = lane >> 4, fm = lane & 15;
-  const T *pa0 = sA + fk * 4 * LDT + wm * (16 * MT) + fm, *pb0 = sB + fk * 4 * LDT + wn * 64 + fm;   // stage 0, step 0
+  const T *pa0 = sA + fk * 4 * LDT + wm * (16 * MT) + fm, *pb0 = sB + fk * 4 * LDT + wn * (16 * NT) + fm;   // stage 0, step 0
 
   gload();
   sstore(0);
@@ -165,18 +166,18 @@ __device__ __forceinline__ void tile_mainloop(Acc<T, MT> &acc, const T *__restri
     const T *pa = pa0 + buf * (BK * LDT), *pb = pb0 + buf * (BK * LDT);
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
-      T a[MT], b[4];
+      T a[MT], b[NT];
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         a[t] = pa[ks * LDT + t * 16];
         if (NEG) a[t] = -a[t];
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) b[t] = pb[ks * LDT + t * 16];
+      for (int t = 0; t < NT; ++t) b[t] = pb[ks * LDT + t * 16];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc.v[mt][nt] = Tr::mfma(a[mt], b[nt], acc.v[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc.v[mt][nt] = Tr::mfma(a[mt], b[nt], acc.v[mt][nt]);
     }
     if (kt + 1 < nkt) sstore(buf ^ 1);
     __syncthreads();
@@ -282,8 +283,8 @@ __device__ __forceinline__ bool xcd_tri_decode(int w, int m, int nlat, int &lat,
 }
 
 // C[tile] = acc (plain store of the 128x128 tile at Cg, leading dimension ldc).
-template <typename T, int MT = 4>
-__device__ __forceinline__ void tile_store(const Acc<T, MT> &acc, T *Cg, int64_t ldc) {
+template <typename T, int MT = 4, int NT = 4>
+__device__ __forceinline__ void tile_store(const Acc<T, MT, NT> &acc, T *Cg, int64_t ldc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
@@ -292,7 +293,7 @@ __device__ __forceinline__ void tile_store(const Acc<T, MT> &acc, T *Cg, int64_t
     for (int r = 0; r < 4; ++r) {
       int row = tile_row<T, MT>(wm, mt, lane, r);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) Cg[(int64_t)row * ldc + tile_col(wn, nt, lane)] = acc.v[mt][nt][r];
+      for (int nt = 0; nt < NT; ++nt) Cg[(int64_t)row * ldc + tile_col<NT>(wn, nt, lane)] = acc.v[mt][nt][r];
     }
 }
 

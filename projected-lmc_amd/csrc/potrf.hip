@@ -32,8 +32,10 @@ struct ColMap {
   int64_t n_pad, wcol0;
 };
 
-// Row panel solve P <- V_rr^T P for block row r.  grid (nU + Taug + nW, q).
-template <typename T>
+// Row panel solve P <- V_rr^T P for block row r.  grid (nU + Taug + nW, q, 4 / NT): NT = 2 splits every 128 x 128 tile
+// into two 64-COLUMN halves -- the solve is in place and every output row needs all 128 input rows of its column,
+// so only a column split keeps workgroups independent -- for launches that would not fill the CUs.
+template <typename T, int NT>
 __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_panel(T *A, int64_t lda, int64_t strideA, int r, ColMap cm,
                                                      const T *__restrict__ Vd, int64_t strideV) {
   __builtin_amdgcn_s_setprio(3);       // chain kernel: ahead of the concurrently running trailing update
@@ -43,12 +45,12 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_panel(T *A, int
   if (t < cm.nU) col0 = (int64_t)(cm.u0 + t) * NB;
   else if (t < cm.nU + cm.Taug) col0 = cm.n_pad + (int64_t)(t - cm.nU) * NB;
   else col0 = cm.wcol0 + (int64_t)(t - cm.nU - cm.Taug) * NB;
-  T *P = A + (int64_t)lat * strideA + (int64_t)r * NB * lda + col0;
+  T *P = A + (int64_t)lat * strideA + (int64_t)r * NB * lda + col0 + (int)blockIdx.z * (32 * NT);
   const T *V = Vd + (int64_t)lat * strideV + (int64_t)r * NB * NB;
-  Acc<T> acc;
+  Acc<T, 4, NT> acc;
   acc.zero();
-  tile_mainloop<T, false>(acc, V, NB, P, lda, NB, smem);
-  tile_store<T>(acc, P, lda);
+  tile_mainloop<T, false, false, 4, NT>(acc, V, NB, P, lda, NB, smem);
+  tile_store<T, 4, NT>(acc, P, lda);
 }
 
 // Rank-(128 g) update of block rows [ib0, ib0 + nrows) with the panel rows of block rows
@@ -201,7 +203,12 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     if (nt == 0) return;
     // algorithmic: triangular solve of nt*NB columns with a 128 x 128 factor = nb^2 flops per column
     ProfScope ps(PK_PANEL, st, q * (double)nt * nb3, q * 2.0 * nt * nb * nb * esz);
-    hipLaunchKernelGGL(k_panel<T>, dim3(nt, q), dim3(NTHREADS), 0, st, A, lda, strideA, r, cm, Vd, strideV);
+    const char *henv = getenv("PLMC_HALF_TILES");
+    const double hthr = henv ? (atoi(henv) == 1 ? 1e30 : (double)atoi(henv)) : 640.0;
+    if ((double)nt * q <= hthr)
+      hipLaunchKernelGGL((k_panel<T, 2>), dim3(nt, q, 2), dim3(NTHREADS), 0, st, A, lda, strideA, r, cm, Vd, strideV);
+    else
+      hipLaunchKernelGGL((k_panel<T, 4>), dim3(nt, q, 1), dim3(NTHREADS), 0, st, A, lda, strideA, r, cm, Vd, strideV);
   };
   // cls: profiler class of the launch -- PK_TRAIL (the big trailing update), PK_TRAIL_HEAD (the rows the next
   // group needs, on the chain stream), PK_TRAIL_ROW (single row inside a group)
