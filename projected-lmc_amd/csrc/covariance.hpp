@@ -57,4 +57,37 @@ __device__ __forceinline__ void kern_value_base_fast(int kind, double r2, double
   kern_value_base<double>(kind, r2, val, base);
 }
 
+
+// Two elements at a time (fp32: the polynomial parts compile to packed v_pk_* instructions; only the square root and
+// the exponential stay scalar).  Same values as kern_value_base_fast.
+__device__ __forceinline__ float  fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ double fast_exp(double x) { return exp(x); }
+__device__ __forceinline__ float  fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+template <typename T> using Pair = T __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ void kern_value_base_pair(int kind, Pair<T> r2, Pair<T> &val, Pair<T> &base) {
+  if (kind == K_RBF) {
+    const Pair<T> a = T(-0.5) * r2;
+    val = Pair<T>{fast_exp(a.x), fast_exp(a.y)};
+    base = val;
+    return;
+  }
+  const Pair<T> r = {fast_sqrt(r2.x > T(0) ? r2.x : T(0)), fast_sqrt(r2.y > T(0) ? r2.y : T(0))};
+  if (kind == K_MATERN12) {
+    val = Pair<T>{fast_exp(-r.x), fast_exp(-r.y)};
+    base = Pair<T>{r.x > T(1e-15) ? val.x / r.x : T(0), r.y > T(1e-15) ? val.y / r.y : T(0)};
+    return;
+  }
+  if (kind == K_MATERN32) {
+    const Pair<T> s = T(1.7320508075688772) * r, e = {fast_exp(-s.x), fast_exp(-s.y)};
+    val = (T(1) + s) * e;
+    base = T(3) * e;
+    return;
+  }
+  const Pair<T> s = T(2.23606797749979) * r, e = {fast_exp(-s.x), fast_exp(-s.y)};
+  const Pair<T> ope = (T(1) + s) * e;
+  val = ope + T(5.0 / 3.0) * r2 * e;
+  base = T(5.0 / 3.0) * ope;
+}
+
 }  // namespace plmc

@@ -16,8 +16,91 @@ namespace plmc {
 
 constexpr int GP = MAX_DIM + 2;      // partial-sum slots per tile: d lengthscales, noise, outputscale
 
+// Gradient sums of an interior tile (strictly above the diagonal, no padded rows or columns, nothing stored): every
+// element is live and counts twice, so the loop has no per-element predicate; KIND is a compile-time constant; two
+// columns (accumulator sub-tiles nt = 2 np, 2 np + 1, 16 columns apart) go through packed arithmetic.
+//     g[k] += 2 os w base df_k^2,    g_os += 2 w val,    w = alpha_i alpha_j - Kinv_ij.
+// The loops are real loops (a fully unrolled body let the scheduler hoist every LDS read and spill): the 16
+// accumulator registers of one sub-tile row mt are parked in LDS -- each thread reads back only what it wrote, no
+// barrier -- so that (np, r) can be runtime indices.  LDS plan (T elements), all inside tile_smem_elems():
+//   ui  [128][DCAP + 4]        scaled inputs of the tile's rows (b128 reads, broadcast inside 16-lane groups)
+//   ujp [64][2 DCAP + 4]       column pairs (c, c + 16) interleaved per dimension: one b128 = two ready pairs
+//   ai  [128], ajp [64][2]     alpha of rows / column pairs
+//   accs[4][256][4]            the parked accumulator slice
+template <int DCAP> struct GradLds {
+  static constexpr int LDI = DCAP + 4, LDP = 2 * DCAP + 4;
+  static constexpr int UI = 0, UJP = UI + NB * LDI, AI = UJP + 64 * LDP, AJP = AI + NB, ACCS = AJP + 128, END = ACCS + 4 * NTHREADS * 4;
+};
+// pair index and slot of tile column c
+__device__ __forceinline__ int col_pair(int c) { return (c >> 6) * 32 + ((c >> 5) & 1) * 16 + (c & 15); }
+__device__ __forceinline__ int col_slot(int c) { return (c >> 4) & 1; }
+
+template <typename T, int DCAP, int KIND>
+__device__ __forceinline__ void grad_tile_interior(const Acc<T> &acc, T *smem, T os, T (&g)[DCAP], T &g_os) {
+  typedef Pair<T> T2;
+  typedef GradLds<DCAP> L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  T2 g2[DCAP];
+#pragma unroll
+  for (int k = 0; k < DCAP; ++k) g2[k] = T2{T(0), T(0)};
+  T2 gos2 = {T(0), T(0)};
+  T *accs = smem + L::ACCS + tid * 4;
+#pragma unroll 1
+  for (int mt = 0; mt < 4; ++mt) {
+    // park acc.v[mt][0..3] (static register indices per case)
+#define PLMC_PARK(M)                                                                                    \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) _Pragma("unroll") for (int r = 0; r < 4; ++r)         \
+      accs[nt * NTHREADS * 4 + r] = acc.v[M][nt][r];
+    if (mt == 0) { PLMC_PARK(0) } else if (mt == 1) { PLMC_PARK(1) } else if (mt == 2) { PLMC_PARK(2) } else { PLMC_PARK(3) }
+#undef PLMC_PARK
+    const T *uir = smem + L::UI + tile_row<T>(wm, mt, lane, 0) * L::LDI;
+    const T *air = smem + L::AI + tile_row<T>(wm, mt, lane, 0);
+#pragma unroll 1
+    for (int np = 0; np < 2; ++np) {
+      const int pr = wn * 32 + np * 16 + (lane & 15);
+      T2 u2[DCAP];
+#pragma unroll
+      for (int k = 0; k < DCAP; ++k) u2[k] = *reinterpret_cast<const T2 *>(smem + L::UJP + pr * L::LDP + 2 * k);
+      const T2 a2 = *reinterpret_cast<const T2 *>(smem + L::AJP + 2 * pr);
+#pragma unroll 1
+      for (int r = 0; r < 4; ++r) {
+        const T2 kin = {accs[(2 * np) * NTHREADS * 4 + r], accs[(2 * np + 1) * NTHREADS * 4 + r]};
+        const T2 w = air[r] * a2 - kin;
+        T xi[DCAP];
+#pragma unroll
+        for (int k = 0; k < DCAP; ++k) xi[k] = uir[r * L::LDI + k];
+        // the differences are formed twice (distance, then gradient weights) instead of keeping d squared pairs
+        // alive across the transcendental part
+        T2 r2 = {T(0), T(0)};
+#pragma unroll
+        for (int k = 0; k < DCAP; ++k) {
+          const T2 df = xi[k] - u2[k];
+          r2 += df * df;
+        }
+        T2 val, base;
+        kern_value_base_pair<T>(KIND, r2, val, base);
+        const T2 c = w * base;
+#pragma unroll
+        for (int k = 0; k < DCAP; ++k) {
+          const T2 df = xi[k] - u2[k];
+          g2[k] += (c * df) * df;
+        }
+        gos2 += w * val;
+      }
+    }
+  }
+  const T os2 = T(2) * os;
+#pragma unroll
+  for (int k = 0; k < DCAP; ++k) g[k] += os2 * (g2[k].x + g2[k].y);
+  g_os += T(2) * (gos2.x + gos2.y);
+}
+
+// occupancy floor: fp32 with up to 8 input dimensions fits 128 registers (4 waves per SIMD, as the update kernels)
+template <typename T, int DCAP> constexpr int KG_MIN_WAVES = sizeof(T) == 8 ? 2 : (DCAP <= 8 ? 4 : (DCAP <= 16 ? 2 : 1));
+
 template <typename T, int DCAP>
-__global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_kinv_grad(int kind, const T *__restrict__ W, int64_t n_pad, int64_t ldw,
+__global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad(int kind, const T *__restrict__ W, int64_t n_pad, int64_t ldw,
                                                          int64_t strideW, const T *__restrict__ alpha,
                                                          const T *__restrict__ X, int n, int d,
                                                          const T *__restrict__ ell, const T *__restrict__ oscale,
@@ -25,10 +108,18 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_kinv_grad(int k
                                                          double *__restrict__ partials, int nlat, int plain) {
   const int m = (int)(n_pad / NB);
   int lat, ib, jb;
-  if (plain) {                         // plain (jb, ib, lat) grid: the default
+  if (plain >= 4) {                    // longest tiles first: jb ascending outermost, latent fastest
+    const int w = blockIdx.x;
+    lat = w % nlat;
+    const int t = w / nlat;
+    jb = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((jb + 1) * (jb + 2) / 2 <= t) ++jb;
+    while (jb * (jb + 1) / 2 > t) --jb;
+    ib = t - jb * (jb + 1) / 2;
+  } else if (plain) {                  // (jb, ib, lat) grid
     jb = blockIdx.x; ib = blockIdx.y; lat = blockIdx.z;
     if (jb < ib) return;
-  } else if (!xcd_tri_decode(blockIdx.x, m, nlat, lat, ib, jb)) return;   // dev knob PLMC_KINV_XCD: XCD-dealt 8 x 8 super-tiles
+  } else if (!xcd_tri_decode(blockIdx.x, m, nlat, lat, ib, jb)) return;   // XCD-dealt 8 x 8 super-tiles
   __shared__ __align__(16) T smem[tile_smem_elems<T>()];
   const T *Wl = W + (int64_t)lat * strideW + (int64_t)jb * NB * ldw;
   Acc<T> acc;
@@ -39,22 +130,38 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_kinv_grad(int k
   // ---- epilogue: stage scaled inputs u = x / ell and alpha for the tile's rows and columns
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  const T *el = ell + (int64_t)lat * d;
+  constexpr bool FAST = sizeof(T) == 4 && GradLds<DCAP>::END <= tile_smem_elems<T>();
+  const bool interior = FAST && ib < jb && (jb + 1) * NB <= n && !Kinv && !kinv_diag && plain != 5;
   const int ldu = d + 1;
-  T *ui = smem;                        // [128][ldu]
+  T *ui = smem;                        // general path: [128][ldu]
   T *uj = ui + NB * ldu;               // [128][ldu]
   T *ai = uj + NB * ldu;               // [128]
   T *aj = ai + NB;                     // [128]
-  const T *el = ell + (int64_t)lat * d;
-  for (int e = tid; e < NB * d; e += NTHREADS) {
-    int r = e / d, k = e % d;
-    int gi = ib * NB + r, gj = jb * NB + r;
-    T inv = T(1) / el[k];
-    ui[r * ldu + k] = gi < n ? X[(int64_t)gi * d + k] * inv : T(0);
-    uj[r * ldu + k] = gj < n ? X[(int64_t)gj * d + k] * inv : T(0);
-  }
-  if (tid < NB) {
-    ai[tid] = alpha[(int64_t)lat * n_pad + ib * NB + tid];
-    aj[tid] = alpha[(int64_t)lat * n_pad + jb * NB + tid];
+  if (interior) {                      // unused dimensions are staged as zeros (they add 0 to every distance)
+    typedef GradLds<DCAP> L;
+    for (int e = tid; e < NB * DCAP; e += NTHREADS) {
+      const int r = e / DCAP, k = e % DCAP;
+      const T inv = k < d ? T(1) / el[k] : T(0);
+      smem[L::UI + r * L::LDI + k] = k < d ? X[(int64_t)(ib * NB + r) * d + k] * inv : T(0);
+      smem[L::UJP + col_pair(r) * L::LDP + 2 * k + col_slot(r)] = k < d ? X[(int64_t)(jb * NB + r) * d + k] * inv : T(0);
+    }
+    if (tid < NB) {
+      smem[L::AI + tid] = alpha[(int64_t)lat * n_pad + ib * NB + tid];
+      smem[L::AJP + 2 * col_pair(tid) + col_slot(tid)] = alpha[(int64_t)lat * n_pad + jb * NB + tid];
+    }
+  } else {
+    for (int e = tid; e < NB * d; e += NTHREADS) {
+      int r = e / d, k = e % d;
+      int gi = ib * NB + r, gj = jb * NB + r;
+      T inv = T(1) / el[k];
+      ui[r * ldu + k] = gi < n ? X[(int64_t)gi * d + k] * inv : T(0);
+      uj[r * ldu + k] = gj < n ? X[(int64_t)gj * d + k] * inv : T(0);
+    }
+    if (tid < NB) {
+      ai[tid] = alpha[(int64_t)lat * n_pad + ib * NB + tid];
+      aj[tid] = alpha[(int64_t)lat * n_pad + jb * NB + tid];
+    }
   }
   __syncthreads();
 
@@ -67,6 +174,16 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_kinv_grad(int k
   for (int k = 0; k < DCAP; ++k) g[k] = T(0);
   T g_noise = T(0), g_os = T(0);
 
+  if constexpr (FAST) {
+    if (interior) {
+      if (kind == K_RBF) grad_tile_interior<T, DCAP, K_RBF>(acc, smem, os, g, g_os);
+      else if (kind == K_MATERN12) grad_tile_interior<T, DCAP, K_MATERN12>(acc, smem, os, g, g_os);
+      else if (kind == K_MATERN32) grad_tile_interior<T, DCAP, K_MATERN32>(acc, smem, os, g, g_os);
+      else grad_tile_interior<T, DCAP, K_MATERN52>(acc, smem, os, g, g_os);
+    }
+  }
+  if (!interior) {
+  // general tile (diagonal, ragged edge, or K^-1 wanted in HBM).
   // mt / nt are unrolled (static accumulator indices); the register r inside an MFMA tile is picked
   // with a select chain -- a runtime-indexed accumulator would be demoted to scratch memory, and a
   // kernel that needs scratch loses most of its occupancy.
@@ -112,6 +229,7 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_kinv_grad(int k
         }
       }
     }
+  }
   }
 
   // ---- workgroup reduction of the d+2 partial sums (wave shuffles, then LDS across 4 waves)
@@ -192,10 +310,14 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
   PLMC_REQUIRE(aligned16(W), "unaligned W");
   hipStream_t st = (hipStream_t)stream;
   const int m = (int)(n_pad / NB);
-  // tile order: the XCD-dealt super-tile order was ahead with the first tile engine (104 vs 98 TF); with the
-  // engine at 142 TF the plain grid is (109 vs 107 TF at q = 8, 91 vs 88 at q = 1), so it is the default
-  const int plain = getenv("PLMC_KINV_XCD") ? 0 : 1;
-  const dim3 grid = plain ? dim3(m, m, q) : dim3(xcd_tri_grid(m, q)), block(NTHREADS);
+  // tile order: longest K range first (jb ascending outermost, latent fastest).  The (jb, ib, lat) grid ran the
+  // long tiles of the last latent at the end of the launch: 112 -> 120 TF at n = 8192, q = 8, 97 -> 118 TF at q = 1,
+  // 77 -> 104 TF at n = 4096 (the same launch with every tile reading one panel pair ran no faster, so operand
+  // locality is not what limits it; an XCD-dealt super-tile order was level with the grid).  Dev knob
+  // PLMC_KINV_ORDER: 0 = XCD-dealt 8 x 8 super-tiles, 1 = (jb, ib, lat) grid, 5 = default order, general epilogue only.
+  const char *ord = getenv("PLMC_KINV_ORDER");
+  const int plain = ord ? atoi(ord) : 4;
+  const dim3 grid = plain >= 4 ? dim3(q * (m * (m + 1) / 2)) : plain ? dim3(m, m, q) : dim3(xcd_tri_grid(m, q)), block(NTHREADS);
   double *part = reinterpret_cast<double *>(partials);
 #define PLMC_LAUNCH_KG(DC)                                                                                          \
   hipLaunchKernelGGL((k_kinv_grad<T, DC>), grid, block, 0, st, kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell,   \
