@@ -189,6 +189,20 @@ int plmc_kernel_vjp_f64(int kind, const double *X1, int n1, const double *X2, in
                         int64_t strideG, double *gX1, double *gEll, double *gOs, int q, void *stream);
 
 /*
+ * Reduced Householder QR of ONE small matrix A (m x n row-major, plmc_qr_max() >= m >= n >= 1) in a single
+ * launch: Q (m x n, orthonormal columns), R (n x n upper triangular, the lower part is written as zeros).
+ * Replaces `torch.linalg.qr(self.H)` of LMCMixingMatrix.QR in bulk mode (projected_lmc.py:864-875, called at
+ * :1015 and :1208) -- on the device ~45 dependent rocSOLVER launches per training step.  LAPACK xGEQR2 / xORG2R
+ * sign convention (R_kk = -sign(a_kk) |a_k:m,k|; a column that is already zero below the diagonal keeps its sign),
+ * i.e. the factors the reference's torch.linalg.qr returns, to rounding.
+ */
+int plmc_qr_max(void);
+int plmc_qr_small_f32(const float *A, int m, int n, int64_t lda, float *Q, int64_t ldq, float *R, int64_t ldr,
+                      void *stream);
+int plmc_qr_small_f64(const double *A, int m, int n, int64_t lda, double *Q, int64_t ldq, double *R, int64_t ldr,
+                      void *stream);
+
+/*
  * Optional per-kernel profiler (measurement only; the reference's counterpart is the wall-clock
  * `time.time()` around its loops, experiments.py:261,284).  While enabled, kernel launches are
  * bracketed by two hipEvents on their launch stream: `on` = 0 none, 1 every kernel class, any other

@@ -32,10 +32,19 @@ static hipEvent_t get_event() {
 // ---- helper stream + ordering events for the look-ahead of the blocked sweep (one per device,
 // created on first use; together with the profiler record this is all the process-global state).
 static hipStream_t g_side[64] = {nullptr};
+static hipStream_t g_side2[64] = {nullptr};
 static hipEvent_t g_sync[64][8] = {{nullptr}};
-hipStream_t side_stream() {
+hipStream_t side_stream(int which) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (which == 1) {                    // second helper: the inverse-factor chain of the sweep
+    if (!g_side2[dev]) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (hipStreamCreateWithPriority(&g_side2[dev], hipStreamNonBlocking, hi) != hipSuccess) g_side2[dev] = nullptr;
+    }
+    return g_side2[dev];
+  }
   if (!g_side[dev]) {
     // highest priority: the latency-bound chain must get CU slots ahead of the queued tail tiles
     int lo = 0, hi = 0;

@@ -197,8 +197,9 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     T *wout = with_inverse ? A + (int64_t)r * NB * lda + wcol0 + (int64_t)r * NB : (T *)nullptr;
     hipLaunchKernelGGL((k_diag<T>), dim3(q), dim3(DIAG_NT), 0, st, A, lda, strideA, r, Vd, strideV, wout, lda, strideA);
   };
-  auto panel = [&](int r, hipStream_t st) {
-    ColMap cm{r + 1, m - 1 - r, Taug, with_inverse ? r : 0, n_pad, wcol0};
+  // part: 0 = every column of the row, 1 = U + augmented columns only, 2 = inverse-factor (W) columns only
+  auto panel = [&](int r, hipStream_t st, int part = 0) {
+    ColMap cm{r + 1, part == 2 ? 0 : m - 1 - r, part == 2 ? 0 : Taug, (with_inverse && part != 1) ? r : 0, n_pad, wcol0};
     const int nt = cm.nU + cm.Taug + cm.nW;
     if (nt == 0) return;
     // algorithmic: triangular solve of nt*NB columns with a 128 x 128 factor = nb^2 flops per column
@@ -212,19 +213,20 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   };
   // cls: profiler class of the launch -- PK_TRAIL (the big trailing update), PK_TRAIL_HEAD (the rows the next
   // group needs, on the chain stream), PK_TRAIL_ROW (single row inside a group)
-  auto update = [&](int ib0, int nrows, int r_lo, int r_hi, hipStream_t st, int cls) {
+  auto update = [&](int ib0, int nrows, int r_lo, int r_hi, hipStream_t st, int cls, int part = 0) {
     if (nrows <= 0) return;
-    ColMap cm{ib0, m - ib0, Taug, with_inverse ? r_hi + 1 : 0, n_pad, wcol0};
+    ColMap cm{ib0, part == 2 ? 0 : m - ib0, part == 2 ? 0 : Taug, (with_inverse && part != 1) ? r_hi + 1 : 0, n_pad, wcol0};
+    if (cm.nU + cm.Taug + cm.nW == 0) return;
     const double depth = (r_hi - r_lo + 1) * nb;
     // algorithmic flops: symmetric rank-k update of the nrows block rows (upper tiles only) + rectangular parts
     const double nr = (double)nrows;
-    const double tilesU = nr * (cm.nU) - nr * (nr - 1) / 2.0;                   // tiles jb >= ib
-    const double flopsU = 2.0 * nb * nb * depth * (tilesU - nr / 2.0);           // diagonal tiles count half
-    const double tilesA = nr * Taug;
+    const double tilesU = part == 2 ? 0.0 : nr * (cm.nU) - nr * (nr - 1) / 2.0;  // tiles jb >= ib
+    const double flopsU = part == 2 ? 0.0 : 2.0 * nb * nb * depth * (tilesU - nr / 2.0);   // diagonal tiles count half
+    const double tilesA = nr * cm.Taug;
     double depthW = 0.0;                                                         // summed panel depth over W columns
     for (int cb = 0; cb < cm.nW; ++cb) depthW += (cb >= r_lo ? (r_hi - cb + 1) : (r_hi - r_lo + 1)) * nb;
-    const double flopsR = 2.0 * nb * nb * nr * (depth * Taug + depthW);
-    const int nfirst = with_inverse ? r_hi - r_lo + 1 : 0;                       // first-touch W columns: no read
+    const double flopsR = 2.0 * nb * nb * nr * (depth * cm.Taug + depthW);
+    const int nfirst = cm.nW > 0 ? r_hi - r_lo + 1 : 0;                          // first-touch W columns: no read
     const double bytes = (2.0 * (tilesU + tilesA + nr * cm.nW) - nr * nfirst) * nb * nb * esz;
     ProfScope ps(cls, st, q * (flopsU + flopsR), q * bytes);
     const int Cn = cm.nU + cm.Taug + cm.nW;
@@ -298,6 +300,23 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       if (r + 1 < g1) update(r + 1, 1, g0, r, s, PK_TRAIL_ROW);
     }
   };
+  // The same chain with the inverse-factor columns taken off the critical path: the next diagonal block depends
+  // only on the U columns, so stream s carries diag / U panel / U row update and stream w follows one row behind
+  // with the W panel and W row update (their A operand is the U panel of the same rows: event e_row).
+  auto chain_split = [&](int gi, hipStream_t s, hipStream_t w, hipEvent_t e_row) {
+    const int g0 = gb[gi], g1 = gb[gi + 1];
+    for (int r = g0; r < g1; ++r) {
+      diag(r, s);
+      panel(r, s, 1);
+      (void)hipEventRecord(e_row, s);
+      (void)hipStreamWaitEvent(w, e_row, 0);
+      panel(r, w, 2);
+      if (r + 1 < g1) {
+        update(r + 1, 1, g0, r, s, PK_TRAIL_ROW, 1);
+        update(r + 1, 1, g0, r, w, PK_TRAIL_ROW, 2);
+      }
+    }
+  };
   // Look-ahead on two streams.  C (helper, high priority) carries the latency-bound work: the chain of
   // each group and the "head" update (the block rows the NEXT chain needs); T (the caller's stream) carries the
   // "tail" update of all other rows.
@@ -318,6 +337,47 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       update(gb[gi + 1], m - gb[gi + 1], gb[gi], gb[gi + 1] - 1, st, PK_TRAIL);
       chain(gi + 1, st);
     }
+    return finish();
+  }
+  // Three streams when the inverse factor is wanted and the launches are wide (dev knob PLMC_WSTREAM=0/1): the W
+  // columns of the chain and of the head rows run on a second helper stream Wc.
+  //   Wc: whead(g) [needs chain_U(g): e_chain, wchain(g): same stream, tail(g-1): e_tail] -> wchain(g+1)
+  //   T : tail(g)  [needs e_chain, e_wchain]
+  hipStream_t Wc = with_inverse ? side_stream(1) : nullptr;
+  hipEvent_t e_row = sync_event(4), e_wchain = sync_event(5), e_wdone = sync_event(6);
+  const char *wenv = getenv("PLMC_WSTREAM");
+  const bool wsplit = Wc && e_row && e_wchain && e_wdone && (wenv ? atoi(wenv) != 0 : q >= 4);
+  if (wsplit) {
+    (void)hipEventRecord(e_entry, st);
+    (void)hipStreamWaitEvent(C, e_entry, 0);
+    (void)hipStreamWaitEvent(Wc, e_entry, 0);
+    chain_split(0, C, Wc, e_row);
+    bool tail_pending = false;
+    for (int gi = 0; gi + 1 < ng; ++gi) {
+      const int g0 = gb[gi], g1 = gb[gi + 1], first = g1, nrest = m - first;
+      const int nhead = gb[gi + 2] - gb[gi + 1];
+      (void)hipEventRecord(e_chain, C);                     // U panels of group gi complete
+      (void)hipEventRecord(e_wchain, Wc);                   // W panels of group gi complete
+      if (tail_pending) {
+        (void)hipStreamWaitEvent(C, e_tail, 0);
+        (void)hipStreamWaitEvent(Wc, e_tail, 0);
+      }
+      update(first, nhead, g0, g1 - 1, C, PK_TRAIL_HEAD, 1);
+      (void)hipStreamWaitEvent(Wc, e_chain, 0);
+      update(first, nhead, g0, g1 - 1, Wc, PK_TRAIL_HEAD, 2);
+      tail_pending = nrest > nhead;
+      if (tail_pending) {
+        (void)hipStreamWaitEvent(st, e_chain, 0);
+        (void)hipStreamWaitEvent(st, e_wchain, 0);
+        update(first + nhead, nrest - nhead, g0, g1 - 1, st, PK_TRAIL);
+        (void)hipEventRecord(e_tail, st);
+      }
+      chain_split(gi + 1, C, Wc, e_row);
+    }
+    (void)hipEventRecord(e_done, C);
+    (void)hipEventRecord(e_wdone, Wc);
+    (void)hipStreamWaitEvent(st, e_done, 0);
+    (void)hipStreamWaitEvent(st, e_wdone, 0);
     return finish();
   }
   hipStream_t Tq = s2 ? s2 : st;

@@ -7,6 +7,7 @@ What it replaces in the reference: the gpytorch evaluation chain behind
 (experiments.py:233) and `loss.backward()` (experiments.py:270); see SURVEY.md 8a rows a1-a4.
 """
 import math
+import os
 import warnings
 
 import torch
@@ -61,7 +62,28 @@ def get_workspace(n, q, naug, dtype, device, need_grad):
             _ws_cache.clear()
         ws = Workspace(n, q, naug, dtype, device, need_grad)
         _ws_cache[key] = ws
+    # a gradient kernel of the previous evaluation may still be reading this workspace on the gradient stream
+    pending = getattr(ws, "pending", None)
+    if pending is not None:
+        torch.cuda.current_stream(device).wait_event(pending)
+        ws.pending = None
     return ws
+
+
+_grad_streams = {}
+
+
+def grad_stream(device):
+    """Stream the fused K^-1 + gradient kernel runs on (one per device; PLMC_GRAD_STREAM=0: the caller's stream).
+    The kernel is the last consumer of the factor and nothing in the forward pass needs its output, so the rest of
+    the forward pass and the part of the backward pass ahead of the latent node (the projection terms of
+    ProjectedLMCmll) -- dozens of launch-bound torch kernels -- run beside it instead of behind it."""
+    if os.environ.get("PLMC_GRAD_STREAM", "1") == "0":
+        return None
+    s = _grad_streams.get(device.index)
+    if s is None:
+        s = _grad_streams[device.index] = torch.cuda.Stream(device)
+    return s
 
 
 def free_workspaces():
@@ -174,9 +196,20 @@ class ExactLatentLogProb(torch.autograd.Function):
             if need_grad:
                 L.call("plmc_wt_matvec", dt, _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.z),
                        _hip.ptr(ws.alpha), q, st)
+                gs = grad_stream(dev)
+                gst = st
+                if gs is not None:
+                    gs.wait_stream(torch.cuda.current_stream(dev))
+                    gst = _hip._c.c_void_p(gs.cuda_stream)
+                    for t in (grad, Xc, ellc, osc):
+                        if t is not None:
+                            t.record_stream(gs)
                 L.call("plmc_kinv_grad", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW,
                        _hip.ptr(ws.alpha), _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad),
-                       None, 0, 0, None, _hip.ptr(ws.partials), q, st)
+                       None, 0, 0, None, _hip.ptr(ws.partials), q, gst)
+                if gs is not None:
+                    ws.pending = torch.cuda.Event()
+                    ws.pending.record(gs)
             return lp, info
 
         # jitter ladder of gpytorch's psd_safe_cholesky [gpytorch-knowledge] (see factorize_checked)
@@ -187,6 +220,7 @@ class ExactLatentLogProb(torch.autograd.Function):
             for i in range(tries):
                 jit = base * (10 ** i)
                 warnings.warn("A not p.d., added jitter of %.1e to the diagonal" % jit, RuntimeWarning)
+                ws = get_workspace(n, q, 1, dt, dev, need_grad)      # waits for the failed attempt's gradient kernel
                 logp, info = enqueue(nzc + jit)
                 if not info.failed():
                     break
@@ -195,6 +229,7 @@ class ExactLatentLogProb(torch.autograd.Function):
                                    "(first failing pivot per latent: %s)" % (jit, info.host.tolist()))
         if need_grad:
             ctx.save_for_backward(grad, ws.alpha[:, :n].clone())
+        ctx.grad_ready = getattr(ws, "pending", None) if need_grad else None
         ctx.d = d
         ctx.has_os = oscale is not None
         ctx.jitter = jit
@@ -203,6 +238,8 @@ class ExactLatentLogProb(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         grad, alpha = ctx.saved_tensors
+        if ctx.grad_ready is not None:
+            torch.cuda.current_stream(alpha.device).wait_event(ctx.grad_ready)
         d = ctx.d
         dt = alpha.dtype
         g64 = gout.to(torch.float64)

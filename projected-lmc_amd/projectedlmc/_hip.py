@@ -32,12 +32,14 @@ _TYPED = {
     "plmc_lmc_cross": [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _P],
     "plmc_lmc_kinv_grad": [_I, _P, _L, _L, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "plmc_kernel_vjp": [_I, _P, _I, _P, _I, _I, _P, _P, _P, _L, _L, _P, _P, _P, _I, _P],
+    "plmc_qr_small": [_P, _I, _I, _L, _P, _L, _P, _L, _P],
 }
 _PLAIN = {
     "plmc_version": ([], _I),
     "plmc_block": ([], _I),
     "plmc_pad": ([_L], _L),
     "plmc_max_dim": ([], _I),
+    "plmc_qr_max": ([], _I),
     "plmc_last_error": ([], _c.c_char_p),
     "plmc_grad_scratch_bytes": ([_L, _I], _L),
     "plmc_lmc_grad_len": ([_I, _I, _I], _L),

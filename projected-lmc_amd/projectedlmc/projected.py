@@ -13,6 +13,7 @@ import torch
 from torch.nn.utils import parametrize
 
 from . import _engine
+from . import _qr
 from . import kernels as _k
 from . import means as _m
 from .constraints import GreaterThan
@@ -67,7 +68,7 @@ class LMCMixingMatrix(torch.nn.Module):
             key = (self.H._version, self.H.data_ptr(), torch.is_grad_enabled(), self.H.dtype, self.H.device)
             cached = getattr(self, "_qr_cache", None)
             if cached is None or cached[0] != key:
-                Qf, Rf = torch.linalg.qr(self.H)
+                Qf, Rf = _qr.qr(self.H)
                 cached = (key, Qf, Rf)
                 object.__setattr__(self, "_qr_cache", cached)
             _, Qf, Rf = cached
