@@ -76,6 +76,91 @@ __global__ __launch_bounds__(NTHREADS) void k_assemble(int kind, const T *__rest
   }
 }
 
+// Up to 8 input dimensions (DCAP in {4, 8}): the thread's 8 columns live in registers as 4 column pairs, the loops
+// over dimensions are unrolled, the kernel kind is a compile-time constant and interior tiles (off the diagonal, no
+// padding) carry no per-element predicate; pairs of columns go through packed arithmetic.  Same formulas
+// and the same accurate exp / sqrt as k_assemble, i.e. the same values up to the order of the distance sum.
+template <typename T, int DCAP, int KIND>
+__device__ __forceinline__ void assemble_tile(const T *ui, const T *uj, int ldu, T os, T nz, T *Al, int64_t lda, int ib,
+                                              int jb, int n, bool edge) {
+  typedef Pair<T> T2;
+  // 32 lanes x 4 consecutive columns = one full 512-byte (fp32) tile row per half wave: whole-row stores
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+  const int c0 = tx * 4;
+  T2 u2[2][DCAP];                                         // [pair][k]
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+    for (int k = 0; k < DCAP; ++k) u2[pp][k] = T2{uj[(c0 + 2 * pp) * ldu + k], uj[(c0 + 2 * pp + 1) * ldu + k]};
+#pragma unroll 2
+  for (int rr = 0; rr < 16; ++rr) {
+    const int r = ty + 8 * rr;
+    const int gi = ib * NB + r;
+    T xi[DCAP];
+#pragma unroll
+    for (int k = 0; k < DCAP; ++k) xi[k] = ui[r * ldu + k];
+    T2 v[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      T2 r2 = {T(0), T(0)};
+#pragma unroll
+      for (int k = 0; k < DCAP; ++k) {
+        const T2 df = xi[k] - u2[pp][k];
+        r2 += df * df;
+      }
+      v[pp] = os * kern_value_pair<T>(KIND, r2);
+    }
+    T o[4] = {v[0].x, v[0].y, v[1].x, v[1].y};
+    if (edge) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int gj = jb * NB + c0 + c;
+        if (gi < n && gj < n) { if (gi == gj) o[c] += nz; }
+        else o[c] = (gi == gj) ? T(1) : T(0);             // identity padding keeps the padded factor trivial
+      }
+    }
+    T *dst = Al + (int64_t)gi * lda + jb * NB + c0;
+    using vec_t = typename Traits<T>::vec_t;
+    constexpr int EPV = Traits<T>::EPV;
+#pragma unroll
+    for (int c = 0; c < 4; c += EPV) {
+      vec_t w;
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) w[e] = o[c + e];
+      *reinterpret_cast<vec_t *>(dst + c) = w;
+    }
+  }
+}
+
+template <typename T, int DCAP>
+__global__ __launch_bounds__(NTHREADS) void k_assemble_small(int kind, const T *__restrict__ X, int n, int d,
+                                                              const T *__restrict__ ell, const T *__restrict__ oscale,
+                                                              const T *__restrict__ noise, T *__restrict__ A,
+                                                              int64_t lda, int64_t strideA) {
+  const int jb = blockIdx.x, ib = blockIdx.y, lat = blockIdx.z;
+  if (jb < ib) return;
+  constexpr int ldu = DCAP + 1;
+  __shared__ T ui[NB * ldu], uj[NB * ldu];
+  const int tid = threadIdx.x;
+  const T *el = ell + (int64_t)lat * d;
+  for (int e = tid; e < NB * DCAP; e += NTHREADS) {      // unused dimensions: zeros (they add 0 to every distance)
+    const int r = e / DCAP, k = e % DCAP;
+    const int gi = ib * NB + r, gj = jb * NB + r;
+    const T inv = k < d ? T(1) / el[k] : T(0);
+    ui[r * ldu + k] = (k < d && gi < n) ? X[(int64_t)gi * d + k] * inv : T(0);
+    uj[r * ldu + k] = (k < d && gj < n) ? X[(int64_t)gj * d + k] * inv : T(0);
+  }
+  __syncthreads();
+  const T os = oscale ? oscale[lat] : T(1);
+  const T nz = noise[lat];
+  T *Al = A + (int64_t)lat * strideA;
+  const bool edge = ib == jb || (jb + 1) * NB > n;
+  if (kind == K_RBF) assemble_tile<T, DCAP, K_RBF>(ui, uj, ldu, os, nz, Al, lda, ib, jb, n, edge);
+  else if (kind == K_MATERN12) assemble_tile<T, DCAP, K_MATERN12>(ui, uj, ldu, os, nz, Al, lda, ib, jb, n, edge);
+  else if (kind == K_MATERN32) assemble_tile<T, DCAP, K_MATERN32>(ui, uj, ldu, os, nz, Al, lda, ib, jb, n, edge);
+  else assemble_tile<T, DCAP, K_MATERN52>(ui, uj, ldu, os, nz, Al, lda, ib, jb, n, edge);
+}
+
 // One thread per element of the first `ncols` augmented columns (n_pad x ncols).
 template <typename T>
 __global__ void k_write_rhs(const T *__restrict__ rhs, int nrhs, int n, T *__restrict__ A, int64_t n_pad,
@@ -129,8 +214,15 @@ int assemble_impl(int kind, const T *X, int n, int d, const T *ell, const T *osc
   const int m = (int)(n_pad / NB);
   size_t smem = 2 * NB * (d + 1) * sizeof(T);
   ProfScope ps(PK_ASSEMBLE, (hipStream_t)stream, 0.0, q * ((double)n_pad * n_pad / 2) * sizeof(T));
-  hipLaunchKernelGGL(k_assemble<T>, dim3(m, m, q), dim3(NTHREADS), smem, (hipStream_t)stream, kind, X, n, d, ell,
-                     oscale, noise, A, lda, strideA);
+  if (d <= 4)
+    hipLaunchKernelGGL((k_assemble_small<T, 4>), dim3(m, m, q), dim3(NTHREADS), 0, (hipStream_t)stream, kind, X, n, d,
+                       ell, oscale, noise, A, lda, strideA);
+  else if (d <= 8)
+    hipLaunchKernelGGL((k_assemble_small<T, 8>), dim3(m, m, q), dim3(NTHREADS), 0, (hipStream_t)stream, kind, X, n, d,
+                       ell, oscale, noise, A, lda, strideA);
+  else
+    hipLaunchKernelGGL(k_assemble<T>, dim3(m, m, q), dim3(NTHREADS), smem, (hipStream_t)stream, kind, X, n, d, ell,
+                       oscale, noise, A, lda, strideA);
   return launch_status(__func__);
 }
 

@@ -90,4 +90,38 @@ template <typename T> __device__ __forceinline__ void kern_value_base_pair(int k
   base = T(5.0 / 3.0) * ope;
 }
 
+// exp / sqrt of the packed assembly path.  fp32: the hardware exp2 on x log2(e) with the rounding error of that
+// product carried along (t + e = x log2(e) to ~2^-45; exp2(t) is good to 1 ulp), so the result is within ~1.5 ulp
+// for every argument -- the plain __expf loses |x| 2^-24 -- at 6 instructions instead of the ~20 of expf; v_sqrt_f32
+// is 1 ulp.  fp64 keeps the library forms.
+__device__ __forceinline__ float asm_exp(float x) {
+  const float L = 1.44269504088896340736f, Ll = 1.9259629911266175e-8f;   // log2(e) = L + Ll
+  const float t = x * L;
+  const float e = __builtin_fmaf(x, L, -t) + x * Ll;
+  const float r = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(r, e * 0.6931471805599453f, r);
+}
+__device__ __forceinline__ double asm_exp(double x) { return exp(x); }
+__device__ __forceinline__ float asm_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double asm_sqrt(double x) { return sqrt(x); }
+#define dexp asm_exp
+#define dsqrt asm_sqrt
+// Two covariance values at a time (assembly kernels).
+template <typename T> __device__ __forceinline__ Pair<T> kern_value_pair(int kind, Pair<T> r2) {
+  if (kind == K_RBF) {
+    const Pair<T> a = T(-0.5) * r2;
+    return Pair<T>{dexp(a.x), dexp(a.y)};
+  }
+  const Pair<T> r = {dsqrt(r2.x > T(0) ? r2.x : T(0)), dsqrt(r2.y > T(0) ? r2.y : T(0))};
+  if (kind == K_MATERN12) return Pair<T>{dexp(-r.x), dexp(-r.y)};
+  if (kind == K_MATERN32) {
+    const Pair<T> s = T(1.7320508075688772) * r;
+    return (T(1) + s) * Pair<T>{dexp(-s.x), dexp(-s.y)};
+  }
+  const Pair<T> s = T(2.23606797749979) * r;
+  return (T(1) + s + T(5.0 / 3.0) * r2) * Pair<T>{dexp(-s.x), dexp(-s.y)};
+}
+#undef dexp
+#undef dsqrt
+
 }  // namespace plmc

@@ -124,3 +124,31 @@ def test_cpu_tensors_fail_loudly(eng):
     X, y, ell, noise, _ = _problem(64, 2, 1)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         eng.exact_latent_log_prob("rbf", X, ell, None, noise, y)
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+@pytest.mark.parametrize("d", [3, 8, 11])
+def test_assembled_covariance_entries_fp32(eng, kind, d):
+    """Entries of the assembled fp32 covariance (packed kernel for d <= 8 with the refined hardware exp, generic kernel
+    above) against the fp64 oracle: within ~4 ulp of the largest entry (fp32 scaled inputs u = x / ell, fp32 polynomial
+    times exp), distances from 0 to far in the tail."""
+    from projectedlmc import _hip
+    n, q = 300, 2
+    X, y, ell, noise, osc = _problem(n, d, q, seed=5)
+    X = X * 3.0                                     # scaled distances up to ~ 20
+    dev = torch.device("cuda:0")
+    ws = eng.get_workspace(n, q, 1, torch.float32, dev, False)
+    L = _hip.lib()
+    f = lambda t: t.to(dev, torch.float32).contiguous()
+    Xc, ec, nc = f(X), f(ell), f(noise)
+    L.call("plmc_assemble", torch.float32, _hip.KIND[kind], _hip.ptr(Xc), n, d, _hip.ptr(ec), None, _hip.ptr(nc),
+           _hip.ptr(ws.A), ws.lda, ws.strideA, q, _hip.stream_ptr(dev))
+    torch.cuda.synchronize()
+    k, nu = KINDS[kind]
+    for i in range(q):
+        # oracle on the fp32-rounded inputs, so that only the arithmetic of the kernel is compared
+        Kref = gm.kernel_matrix(k, Xc.double().cpu(), Xc.double().cpu(), ec[i].double().cpu()[None], nu=nu)[0]
+        Kref = Kref + nc[i].double().cpu() * torch.eye(n, dtype=torch.float64)
+        got = ws.A[i, :n, :n].double().cpu()
+        err = (got - Kref).triu().abs().max()
+        assert float(err) < 6e-7 * (1.0 + float(nc[i])), (kind, d, float(err))
