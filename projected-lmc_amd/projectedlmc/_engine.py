@@ -166,10 +166,13 @@ class ExactLatentLogProb(torch.autograd.Function):
     analytic gradient computed in the same pass.
 
     forward(X (n,d), ell (q,d), oscale (q)|None, noise (q), y (q,n), kind) -> (q,)
+    forward(..., kind, table) with table (q, d+2) float64: the hyper-parameter gradients are written into `table` and
+    NOT returned by this node's backward -- the two-node form exact_latent_log_prob builds when a gradient stream
+    exists (see _HyperGrad).
     """
 
     @staticmethod
-    def forward(ctx, X, ell, oscale, noise, y, kind):
+    def forward(ctx, X, ell, oscale, noise, y, kind, table=None):
         _hip.require_device(X, ell, noise, y)
         L = _hip.lib()
         dt, dev = y.dtype, y.device
@@ -179,11 +182,11 @@ class ExactLatentLogProb(torch.autograd.Function):
         d = X.shape[1]
         if d > L.cdll.plmc_max_dim():
             raise ValueError("input dimension %d exceeds plmc_max_dim()=%d" % (d, L.cdll.plmc_max_dim()))
-        need_grad = any(ctx.needs_input_grad[1:5])
+        need_grad = any(ctx.needs_input_grad[1:5]) or table is not None
         Xc, ellc, osc, nzc, yc = (_contig(t, dt) for t in (X, ell, oscale, noise, y))
         ws = get_workspace(n, q, 1, dt, dev, need_grad)
         st = _hip.stream_ptr(dev)
-        grad = torch.empty(q, d + 2, dtype=torch.float64, device=dev) if need_grad else None
+        grad = table if table is not None else (torch.empty(q, d + 2, dtype=torch.float64, device=dev) if need_grad else None)
         check = settings.check_cholesky.on()
 
         def enqueue(noise_eff):
@@ -233,25 +236,90 @@ class ExactLatentLogProb(torch.autograd.Function):
         ctx.d = d
         ctx.has_os = oscale is not None
         ctx.jitter = jit
+        ctx.table_out = table is not None
         return logp.to(dt)
 
     @staticmethod
     def backward(ctx, gout):
         grad, alpha = ctx.saved_tensors
+        dt = alpha.dtype
+        if ctx.table_out:                  # the hyper-parameter gradients flow through _HyperGrad
+            return None, None, None, None, -(gout[:, None].to(dt) * alpha), None, None
         if ctx.grad_ready is not None:
             torch.cuda.current_stream(alpha.device).wait_event(ctx.grad_ready)
         d = ctx.d
-        dt = alpha.dtype
         g64 = gout.to(torch.float64)
         g_ell = g64[:, None] * grad[:, :d]
         g_noise = g64 * grad[:, d]
         g_os = g64 * grad[:, d + 1] if ctx.has_os else None
         g_y = -(gout[:, None].to(dt) * alpha)
-        return None, g_ell, g_os, g_noise, g_y, None
+        return None, g_ell, g_os, g_noise, g_y, None, None
 
 
-def exact_latent_log_prob(kind, X, ell, oscale, noise, y):
-    return ExactLatentLogProb.apply(X, ell, oscale, noise, y, kind)
+class _HyperGrad(torch.autograd.Function):
+    """Second autograd node of the exact log-prob: contributes 0 to the value and carries d logp / d(ell, oscale,
+    noise) from the gradient table.  It is applied with the gradient stream current, so autograd runs its backward on
+    that stream -- behind the K^-1 + gradient kernel in stream order, no host wait -- and makes the caller's stream wait
+    only where the first consumer of these gradients runs (the constraint transforms of the kernel parameters, created
+    early in the forward pass and therefore late in the backward pass).  The backward of the projection (d logp / dy
+    -> mixing matrix, ~50 launch-bound kernels) is queued ahead of that wait and runs beside the gradient kernel."""
+
+    @staticmethod
+    def forward(ctx, ell, oscale, noise, table, zero):
+        ctx.save_for_backward(table)
+        ctx.d = ell.shape[1]
+        ctx.has_os = oscale is not None
+        return zero.detach()
+
+    @staticmethod
+    def backward(ctx, gout):
+        (table,) = ctx.saved_tensors
+        d = ctx.d
+        g64 = gout.to(torch.float64)
+        g_ell = g64[:, None] * table[:, :d]
+        g_noise = g64 * table[:, d]
+        g_os = g64 * table[:, d + 1] if ctx.has_os else None
+        return g_ell, g_os, g_noise, None, None
+
+
+_zeros = {}
+
+
+class HyperGradHandle:
+    __slots__ = ("table", "hz")
+
+
+def prepare_hyper_grad(ell, oscale, noise):
+    """Create the hyper-parameter gradient node (_HyperGrad) NOW and return a handle for exact_latent_log_prob, or
+    None when there is nothing to do (no gradient stream, nothing requires grad, host tensors).
+    Autograd runs backward nodes in reverse creation order, and the caller's stream is made to wait for the gradient
+    stream as soon as this node has run; a caller that creates it BEFORE the graph that produces y (the projection
+    of ProjectedLMCmll: QR, triangular solve, GEMMs) gets that graph's backward queued ahead of the wait."""
+    hyper = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (ell, oscale, noise))
+    gs = grad_stream(ell.device) if (hyper and ell.is_cuda) else None
+    if gs is None:
+        return None
+    q, d = ell.shape
+    key = (ell.device.index, ell.dtype, q)
+    zero = _zeros.get(key)
+    if zero is None:
+        zero = _zeros[key] = torch.zeros(q, dtype=ell.dtype, device=ell.device)
+        torch.cuda.current_stream(ell.device).synchronize()
+    h = HyperGradHandle()
+    h.table = torch.empty(q, d + 2, dtype=torch.float64, device=ell.device)
+    with torch.cuda.stream(gs):
+        h.hz = _HyperGrad.apply(ell, oscale, noise, h.table, zero)
+    return h
+
+
+def exact_latent_log_prob(kind, X, ell, oscale, noise, y, hyper=None):
+    if hyper is None:
+        hyper = prepare_hyper_grad(ell, oscale, noise)
+    if hyper is None:
+        return ExactLatentLogProb.apply(X, ell, oscale, noise, y, kind)
+    det = lambda t: None if t is None else t.detach()
+    lp = ExactLatentLogProb.apply(X, det(ell), det(oscale), det(noise), y, kind, hyper.table)
+    return lp + hyper.hz
 
 
 def exact_loo(kind, X, ell, oscale, noise, y):

@@ -15,6 +15,7 @@ from torch.nn.utils import parametrize
 from . import _engine
 from . import _qr
 from . import kernels as _k
+from .kernels import LazyKernel
 from . import means as _m
 from .constraints import GreaterThan
 from .distributions import MultivariateNormal, MultitaskMultivariateNormal, KroneckerSumCovariance
@@ -337,16 +338,23 @@ class ProjectedLMCmll(ExactMarginalLogLikelihood):
             raise RuntimeError("ExactMarginalLogLikelihood can only operate on Gaussian random variables")
         model = self.model
         num_data = latent_function_dist.event_shape.numel()
-        proj_target = model.project_data(target)                         # q x n
+        # (reference order :1200-1201 is projection, then likelihood; the two are independent.  The hyper-parameter
+        # gradient node is created before the projection graph on purpose -- see _engine.prepare_hyper_grad.)
         latent_output = self.likelihood(latent_function_dist, *params)
         ids = model.latent_ids
-        if ids is None:
+        c = latent_output.lazy_covariance_matrix
+        exact = isinstance(c, LazyKernel) and c.noise is not None
+        if exact:
+            sel = (lambda t: t) if ids is None else (lambda t: t[ids])   # this rank's latents only
+            ell_s, nz_s = sel(c.ell), sel(c.noise.reshape(-1))
+            osc = None if c.oscale is None else sel(c.oscale)
+            hyper = _engine.prepare_hyper_grad(ell_s, osc, nz_s)
+        proj_target = model.project_data(target)                         # q x n
+        if exact:
+            diff = proj_target - latent_output.loc                       # the latent means are zero (ZeroMean enforced)
+            latent_res = _engine.exact_latent_log_prob(c.kind, c.x1, ell_s, osc, nz_s, sel(diff), hyper=hyper)
+        else:
             latent_res = latent_output.log_prob(proj_target)
-        else:                                                            # this rank's latents only
-            c = latent_output.lazy_covariance_matrix
-            osc = None if c.oscale is None else c.oscale[ids]
-            latent_res = _engine.exact_latent_log_prob(c.kind, c.x1, c.ell[ids], osc, c.noise.reshape(-1)[ids],
-                                                       proj_target[ids])
         latent_res = self._add_other_terms(latent_res, params).sum() / num_data
 
         p, q = model.n_tasks, model.n_latents

@@ -29,7 +29,7 @@ def _worker(rank, world, port, q, ret):
     from oracle import gp_math as gm
     kinds = {"rbf": ("rbf", 2.5), "matern52": ("matern", 2.5)}
 
-    def fake_log_prob(kind, X, ell, oscale, noise, y):                 # oracle stand-in for the HIP call
+    def fake_log_prob(kind, X, ell, oscale, noise, y, hyper=None):     # oracle stand-in for the HIP call
         k, nu = kinds[kind]
         return gm.exact_latent_log_prob(k, X, ell, noise, y, oscale, nu)
     _engine.exact_latent_log_prob = fake_log_prob

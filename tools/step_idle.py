@@ -5,7 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ming = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 short = lambda r: r["Kernel_Name"].replace("void ", "").replace("plmc::", "").split("(")[0][:34]
-asm = [i for i, r in enumerate(rows) if "k_assemble<" in r["Kernel_Name"]]
+asm = [i for i, r in enumerate(rows) if ("k_assemble<" in r["Kernel_Name"] or "k_assemble_small<" in r["Kernel_Name"])]
 a, b = asm[-2], asm[-1]
 step = rows[a:b]
 t0, tend = int(step[0]["Start_Timestamp"]), int(rows[b]["Start_Timestamp"])

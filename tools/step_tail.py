@@ -3,7 +3,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ends = [i for i, r in enumerate(rows) if "k_reduce_grad" in r["Kernel_Name"]]
-starts = [i for i, r in enumerate(rows) if "k_assemble<" in r["Kernel_Name"] or "k_assemble(" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if ("k_assemble<" in r["Kernel_Name"] or "k_assemble_small<" in r["Kernel_Name"]) or "k_assemble(" in r["Kernel_Name"]]
 e = ends[-2]
 s = min(i for i in starts if i > e)
 t0 = int(rows[e]["End_Timestamp"])

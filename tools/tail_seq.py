@@ -3,7 +3,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 kg = [i for i, r in enumerate(rows) if "k_kinv_grad" in r["Kernel_Name"]]
-asm = [i for i, r in enumerate(rows) if "k_assemble<" in r["Kernel_Name"]]
+asm = [i for i, r in enumerate(rows) if ("k_assemble<" in r["Kernel_Name"] or "k_assemble_small<" in r["Kernel_Name"])]
 e = kg[-2]; s = min(i for i in asm if i > e)
 t0 = int(rows[e]["Start_Timestamp"]); t1 = int(rows[e]["End_Timestamp"])
 print("kinv_grad %.1f us; next assemble starts %.1f us after its end" % ((t1 - t0) / 1e3, (int(rows[s]["Start_Timestamp"]) - t1) / 1e3))
