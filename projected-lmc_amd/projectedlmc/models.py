@@ -190,7 +190,11 @@ class ExactGP(torch.nn.Module):
             x = x.unsqueeze(-1)
         if self.training:
             tx = self.train_inputs[0]
-            if not (x is tx or (x.shape == tx.shape and torch.equal(x, tx))):
+            # same object or same memory: equal without looking (torch.equal on device tensors is a host sync that
+            # drains the queue at the head of every training step)
+            same = x is tx or (x.shape == tx.shape and x.dtype == tx.dtype and x.device == tx.device
+                               and x.data_ptr() == tx.data_ptr() and x.stride() == tx.stride())
+            if not (same or (x.shape == tx.shape and torch.equal(x, tx))):
                 raise RuntimeError("You must train on the training inputs!")
             return self.forward(x)
         return self._posterior(x, **kwargs)
