@@ -9,6 +9,7 @@ from projectedlmc import _hip
 n, d, p, q = int(sys.argv[1]) if len(sys.argv) > 1 else 2048, 8, 8, 4
 dt = torch.float64 if (len(sys.argv) <= 2 or sys.argv[2] == "f64") else torch.float32
 torch.set_default_dtype(dt)
+torch.manual_seed(0)
 g = torch.Generator().manual_seed(0)
 X = 2 * torch.rand(n, d, generator=g) - 1
 Y = torch.randn(n, p, generator=g)
