@@ -275,11 +275,8 @@ class _HyperGrad(torch.autograd.Function):
     def backward(ctx, gout):
         (table,) = ctx.saved_tensors
         d = ctx.d
-        g64 = gout.to(torch.float64)
-        g_ell = g64[:, None] * table[:, :d]
-        g_noise = g64 * table[:, d]
-        g_os = g64 * table[:, d + 1] if ctx.has_os else None
-        return g_ell, g_os, g_noise, None, None
+        g = (table * gout[:, None]).to(gout.dtype)          # fp64 product, one cast; the three gradients are views
+        return g[:, :d], (g[:, d + 1] if ctx.has_os else None), g[:, d], None, None
 
 
 _zeros = {}
