@@ -158,3 +158,36 @@ def test_fp32_projected_step_meets_the_1e4_target(plmc):
     mll = plmc.ProjectedLMCmll(m.likelihood, m)
     val = float(mll(m(X.float().to(DEV)), Y.float().to(DEV)))
     assert abs(val - ref) < 1e-4 * abs(ref), (val, ref)
+
+
+@pytest.mark.parametrize("q,world", [(3, 2), (4, 4)])
+def test_latent_shards_sum_to_the_unsharded_step(plmc, q, world):
+    """The per-rank path of the multi-GPU run (latent_shard -> only this rank's latents go through the HIP engine,
+    hyper-parameter gradient node included) on one GPU: the loss shares and the gradients of all `world` shards add
+    up to the un-sharded loss and gradients (what the fused all-reduce of parallel.sync_loss_and_grads forms)."""
+    n, d, p = 300, 3, 6
+    X, Y = _data(n, d, p, seed=21)
+    Xd, Yd = X.to(DEV), Y.to(DEV)
+
+    def build(shard):
+        torch.manual_seed(2)
+        m = _model(plmc, X, Y, q, plmc.MaternKernel, init_lmc_coeffs=True, latent_shard=shard, **VARIANTS["PLMC"])
+        m = perturb_(m.double()).to(DEV)
+        m.train(); m.likelihood.train()
+        return m, plmc.ProjectedLMCmll(m.likelihood, m)
+
+    m0, mll0 = build(None)
+    loss0 = -mll0(m0(Xd), Yd)
+    loss0.backward()
+    total, grads = 0.0, None
+    for rank in range(world):
+        m1, mll1 = build((rank, world))
+        assert m1.latent_ids == list(range(rank, q, world))
+        share = -mll1(m1(Xd), Yd)
+        share.backward()
+        total = total + float(share.detach())
+        gs = [torch.zeros_like(prm) if prm.grad is None else prm.grad.clone() for prm in m1.parameters()]
+        grads = gs if grads is None else [a + b for a, b in zip(grads, gs)]
+    assert abs(total - float(loss0)) < 1e-10 * abs(float(loss0)), (total, float(loss0))
+    for (name, prm), g in zip(m0.named_parameters(), grads):
+        assert torch.allclose(prm.grad, g, rtol=1e-8, atol=1e-11), (name, (prm.grad - g).abs().max())
