@@ -87,12 +87,13 @@ def cpu_baseline(X, Y, model_cpu_state, n_latents, budget_latents=4):
         lp, *_ = cpu_step.latent_step("matern", X, ell[j], noise[j], ytil[j], nu=2.5)
         ts.append(time.time() - t0)
     t = sum(ts[1:]) / len(ts[1:]) if len(ts) > 1 else ts[0]          # mean over the sampled latents (~10 s of CPU work)
-    # fp64 forward-only value of latent 0 for the log-likelihood relative-error check
-    lp64 = cpu_step.latent_logp("matern", X.double(), ell[0].double(), noise[0].double(), ytil[0].double(), nu=2.5)
+    # fp64 value and analytic gradient of latent 0 for the relative-error checks
+    lp64, ge64, gn64, _ = cpu_step.latent_step("matern", X.double(), ell[0].double(), noise[0].double(), ytil[0].double(), nu=2.5)
+    g64 = torch.cat([ge64.reshape(-1), gn64.reshape(-1)])
     return dict(value=1.0 / (n_latents * t), unit="iters/sec", cores=torch.get_num_threads(), kind="port",
                 sample="%d of %d latent exact-GP MLL+gradient evaluations at n=%d (fp32 dense Cholesky + inverse, "
                        "torch CPU), scaled to the full %d-latent step; %.1f s per latent" % (
-                           budget_latents, n_latents, n, n_latents, t)), float(lp64)
+                           budget_latents, n_latents, n, n_latents, t)), float(lp64), g64
 
 
 def main():
@@ -169,11 +170,18 @@ def main():
         torch.cuda.synchronize(dev)
 
     # per-latent log-prob at the initial parameters (untimed; for the rel-err check vs the fp64 oracle)
+    from projectedlmc import _engine
     with torch.no_grad():
-        from projectedlmc import _engine
         lp_init = _engine.exact_latent_log_prob("matern52", Xd, cpu_state[0].to(dev), None, cpu_state[1].to(dev),
                                                 cpu_state[2].to(dev))
         lp0_gpu = float(lp_init[0]) if rank == 0 else 0.0
+    # ... and its analytic gradient for latent 0 (lengthscales, noise), same check at full size
+    g0_gpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        e0 = cpu_state[0][:1].to(dev).requires_grad_()
+        z0 = cpu_state[1][:1].to(dev).requires_grad_()
+        _engine.exact_latent_log_prob("matern52", Xd, e0, None, z0, cpu_state[2][:1].to(dev)).sum().backward()
+        g0_gpu = torch.cat([e0.grad.reshape(-1), z0.grad.reshape(-1)]).double().cpu()
     def note(msg):
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
@@ -283,11 +291,15 @@ def main():
         note("%.2f ms/step on %d GPU(s)" % (1e3 * elapsed / args.steps, world))
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle on %d host cores (bounded sample: 4 of %d latents) ..." % (host_cores(), q))
-            cb, lp_cpu = cpu_baseline(X, Y, cpu_state, q)
+            cb, lp_cpu, g_cpu = cpu_baseline(X, Y, cpu_state, q)
             res["cpu_baseline"] = cb
             res["speedup_vs_cpu"] = its / cb["value"]
             res["loglik_rel_err"] = abs(lp0_gpu - lp_cpu) / abs(lp_cpu)
             res["loglik_check"] = "latent 0 log N(y~;0,K+s2 I) at initial parameters: fp32 HIP %.6f vs fp64 oracle %.6f" % (lp0_gpu, lp_cpu)
+            if g0_gpu is not None:
+                res["grad_rel_err"] = float((g0_gpu - g_cpu).norm() / g_cpu.norm())
+                res["grad_check"] = ("latent 0 d logp / d(lengthscales, noise) at initial parameters, |HIP fp32 - fp64 oracle| / "
+                                     "|fp64 oracle| over the %d components" % g_cpu.numel())
         res["first_loss"] = first_loss
         print(json.dumps(res))
     if world > 1:
