@@ -70,6 +70,7 @@ template <typename T, int ROLE, int MT = 4>
 __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, int64_t lda, int64_t strideA, int ib0, int r_lo, int r_hi,
                                                       ColMap cm) {
   if (ROLE == 1) __builtin_amdgcn_s_setprio(3);
+  if (ROLE == 2) __builtin_amdgcn_s_setprio(2);       // head rows: the next chain waits for them
   // plain row-major tile order: an XCD-dealt super-block order (xcd_tri_decode, gemm_core.hpp) was 3 % faster for a
   // launch that has the GPU to itself and 25 % slower in the sweep, where launches from three streams
   // interleave and "workgroup w lands on XCD w % 8" no longer holds
