@@ -198,6 +198,10 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     T *wout = with_inverse ? A + (int64_t)r * NB * lda + wcol0 + (int64_t)r * NB : (T *)nullptr;
     hipLaunchKernelGGL((k_diag<T>), dim3(q), dim3(DIAG_NT), 0, st, A, lda, strideA, r, Vd, strideV, wout, lda, strideA);
   };
+  // launches with few tiles run on half tiles (dev knob PLMC_HALF_TILES: 0 = never, 1 = always, N > 1 = tile-count
+  // threshold); read once per sweep, not per launch
+  const char *henv = getenv("PLMC_HALF_TILES");
+  const double hthr = henv ? (atoi(henv) == 1 ? 1e30 : (double)atoi(henv)) : 640.0;
   // part: 0 = every column of the row, 1 = U + augmented columns only, 2 = inverse-factor (W) columns only
   auto panel = [&](int r, hipStream_t st, int part = 0) {
     ColMap cm{r + 1, part == 2 ? 0 : m - 1 - r, part == 2 ? 0 : Taug, (with_inverse && part != 1) ? r : 0, n_pad, wcol0};
@@ -205,8 +209,6 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     if (nt == 0) return;
     // algorithmic: triangular solve of nt*NB columns with a 128 x 128 factor = nb^2 flops per column
     ProfScope ps(PK_PANEL, st, q * (double)nt * nb3, q * 2.0 * nt * nb * nb * esz);
-    const char *henv = getenv("PLMC_HALF_TILES");
-    const double hthr = henv ? (atoi(henv) == 1 ? 1e30 : (double)atoi(henv)) : 640.0;
     if ((double)nt * q <= hthr)
       hipLaunchKernelGGL((k_panel<T, 2>), dim3(nt, q, 2), dim3(NTHREADS), 0, st, A, lda, strideA, r, cm, Vd, strideV);
     else
@@ -232,8 +234,6 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     ProfScope ps(cls, st, q * (flopsU + flopsR), q * bytes);
     const int Cn = cm.nU + cm.Taug + cm.nW;
     // chain launches with few tiles (single-latent shards) run on 64-row half tiles: twice the workgroups
-    const char *henv = getenv("PLMC_HALF_TILES");          // dev knob: 0 = never, 1 = always, N > 1 = tile-count threshold
-    const double hthr = henv ? (atoi(henv) == 1 ? 1e30 : (double)atoi(henv)) : 640.0;
     const bool half = cls != PK_TRAIL && (double)Cn * nrows * q <= hthr;
     const dim3 grid(Cn, half ? 2 * nrows : nrows, q);
     if (cls == PK_TRAIL_ROW) {
