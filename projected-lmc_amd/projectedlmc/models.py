@@ -4,6 +4,8 @@ engine instead of gpytorch.
 """
 import warnings
 
+import weakref
+
 import torch
 
 from . import _engine
@@ -11,6 +13,10 @@ from . import kernels as _k
 from . import means as _m
 from .distributions import MultivariateNormal, MultitaskMultivariateNormal
 from .likelihoods import GaussianLikelihood
+
+# model -> (input tensor, version, training input, version) already compared equal (kept outside the module's
+# __dict__: weak references do not pickle)
+_TRAIN_INPUT_SEEN = weakref.WeakKeyDictionary()
 
 
 # ---------------------------------------------------------------------------------------- helpers
@@ -190,11 +196,19 @@ class ExactGP(torch.nn.Module):
             x = x.unsqueeze(-1)
         if self.training:
             tx = self.train_inputs[0]
-            # same object or same memory: equal without looking (torch.equal on device tensors is a host sync that
-            # drains the queue at the head of every training step)
+            # same object or same memory: equal without looking.  Otherwise torch.equal -- a host sync that drains the
+            # queue at the head of every training step -- is run once per (input tensor, version) pair and remembered:
+            # an in-place change of either tensor bumps its version and brings the comparison back.
             same = x is tx or (x.shape == tx.shape and x.dtype == tx.dtype and x.device == tx.device
                                and x.data_ptr() == tx.data_ptr() and x.stride() == tx.stride())
-            if not (same or (x.shape == tx.shape and torch.equal(x, tx))):
+            if not same:
+                seen = _TRAIN_INPUT_SEEN.get(self)
+                if seen is not None and seen[0]() is x and seen[1] == x._version and seen[2]() is tx and seen[3] == tx._version:
+                    same = True
+                elif x.shape == tx.shape and torch.equal(x, tx):
+                    same = True
+                    _TRAIN_INPUT_SEEN[self] = (weakref.ref(x), x._version, weakref.ref(tx), tx._version)
+            if not same:
                 raise RuntimeError("You must train on the training inputs!")
             return self.forward(x)
         return self._posterior(x, **kwargs)
