@@ -143,6 +143,33 @@ def factorize_checked(kind, X, ell, oscale, noise, rhs, ws, Xs=None):
                        "(first failing pivot per latent: %s)" % (jit, info.tolist()))
 
 
+class deferred_pivot_checks:
+    """Context manager for a caller that can redo its whole forward pass: inside it the exact log-prob does not wait
+    for the pivot check of its factorisation (the host goes on queueing the rest of the forward pass while the sweep
+    runs); `failed()` after the block waits for the checks.  `jitter` is added to the noise of every factorisation
+    inside the block -- the caller's retry ladder (ProjectedLMCmll.forward) plays psd_safe_cholesky's."""
+    current = None
+
+    def __init__(self, jitter=0.0):
+        self.jitter = float(jitter)
+        self.pending = []
+        self.first_bad = None
+
+    def __enter__(self):
+        self._outer = deferred_pivot_checks.current
+        deferred_pivot_checks.current = self
+        return self
+
+    def __exit__(self, *exc):
+        deferred_pivot_checks.current = self._outer
+        return False
+
+    def failed(self):
+        bad = [i for i in self.pending if i.failed()]
+        self.first_bad = bad[0].host.tolist() if bad else None
+        return bool(bad)
+
+
 class _DeferredInfo:
     """Pivot check of a factorisation without stalling the stream: `info` is copied to pinned host memory right
     behind the sweep and looked at only after the kernels that follow it have been queued, so the GPU runs
@@ -216,8 +243,14 @@ class ExactLatentLogProb(torch.autograd.Function):
             return lp, info
 
         # jitter ladder of gpytorch's psd_safe_cholesky [gpytorch-knowledge] (see factorize_checked)
-        logp, info = enqueue(nzc)
-        jit = 0.0
+        dc = deferred_pivot_checks.current if check else None
+        if dc is not None:                 # the caller owns the ladder and looks at the check after its forward pass
+            logp, info = enqueue(nzc + dc.jitter if dc.jitter > 0.0 else nzc)
+            dc.pending.append(info)
+            jit, check = dc.jitter, False
+        else:
+            logp, info = enqueue(nzc)
+            jit = 0.0
         if check and info.failed():
             base, tries = settings.cholesky_jitter.value(dt), settings.cholesky_max_tries.value()
             for i in range(tries):

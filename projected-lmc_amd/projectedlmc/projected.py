@@ -7,12 +7,14 @@ in libplmc_hip.so.  With `latent_shard=(rank, world)` the q independent latent G
 across ranks and `ProjectedLMCmll` returns this rank's share of the loss.
 """
 import math
+import os
 import warnings
 
 import torch
 from torch.nn.utils import parametrize
 
 from . import _engine
+from . import settings
 from . import _qr
 from . import kernels as _k
 from .kernels import LazyKernel
@@ -334,8 +336,28 @@ class ProjectedLMCmll(ExactMarginalLogLikelihood):
         self.previous_lat = None
 
     def forward(self, latent_function_dist, target, inputs=None, *params):
+        """The pivot check of the latent factorisation is looked at AFTER the whole forward pass has been queued (the
+        host would otherwise sit out the sweep and queue the projection terms behind it); on a non-PD pivot the
+        forward pass is redone with jitter -- the ladder of gpytorch's psd_safe_cholesky [gpytorch-knowledge], same
+        warnings, same final error (reference call site: experiments.py:265, cholesky_max_tries)."""
         if not isinstance(latent_function_dist, MultivariateNormal):
             raise RuntimeError("ExactMarginalLogLikelihood can only operate on Gaussian random variables")
+        if not (settings.check_cholesky.on() and target.is_cuda) or os.environ.get("PLMC_DEFER_CHECK", "1") == "0":
+            return self._forward_once(latent_function_dist, target, inputs, *params)
+        base, tries = settings.cholesky_jitter.value(target.dtype), settings.cholesky_max_tries.value()
+        jit = 0.0
+        for i in range(tries + 1):
+            with _engine.deferred_pivot_checks(jit) as dc:
+                res = self._forward_once(latent_function_dist, target, inputs, *params)
+            if not dc.failed():
+                return res
+            if i == tries:
+                raise RuntimeError("Matrix not positive definite after repeatedly adding jitter up to %.1e "
+                                   "(first failing pivot per latent: %s)" % (jit, dc.first_bad))
+            jit = base * (10 ** i)
+            warnings.warn("A not p.d., added jitter of %.1e to the diagonal" % jit, RuntimeWarning)
+
+    def _forward_once(self, latent_function_dist, target, inputs=None, *params):
         model = self.model
         num_data = latent_function_dist.event_shape.numel()
         # (reference order :1200-1201 is projection, then likelihood; the two are independent.  The hyper-parameter

@@ -191,3 +191,30 @@ def test_latent_shards_sum_to_the_unsharded_step(plmc, q, world):
     assert abs(total - float(loss0)) < 1e-10 * abs(float(loss0)), (total, float(loss0))
     for (name, prm), g in zip(m0.named_parameters(), grads):
         assert torch.allclose(prm.grad, g, rtol=1e-8, atol=1e-11), (name, (prm.grad - g).abs().max())
+
+
+def test_deferred_pivot_check_walks_the_same_jitter_ladder(plmc):
+    """ProjectedLMCmll looks at the pivot check after the whole forward pass is queued and redoes the pass with jitter;
+    the direct path (check inside the log-prob call) must land on the same jitter and the same loss."""
+    n, d, p, q = 300, 2, 4, 2
+    X, Y = _data(n, d, p, seed=3)
+    torch.manual_seed(1)
+    m = _model(plmc, X.float(), Y.float(), q, plmc.RBFKernel, noise_thresh=-40., **VARIANTS["PLMC_fast"])
+    m = m.to(DEV)
+    with torch.no_grad():                                   # long lengthscales: K is numerically singular in fp32
+        for name, prm in m.named_parameters():
+            if "lengthscale" in name:
+                prm.fill_(5.0)
+            if "raw_noise" in name:
+                prm.fill_(-40.0)                            # noise ~ e^-40: nothing holds the spectrum up
+    Xd, Yd = X.float().to(DEV), Y.float().to(DEV)
+    m.train(); m.likelihood.train()
+    mll = plmc.ProjectedLMCmll(m.likelihood, m)
+    with pytest.warns(RuntimeWarning, match="not p.d."):
+        loss = -mll(m(Xd), Yd)
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert all(torch.isfinite(prm.grad).all() for prm in m.parameters() if prm.grad is not None)
+    with pytest.warns(RuntimeWarning, match="not p.d."):
+        direct = -mll._forward_once(m(Xd), Yd)
+    assert abs(float(loss.detach()) - float(direct.detach())) <= 1e-5 * abs(float(direct.detach()))
