@@ -30,20 +30,25 @@ class SmallQR(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gQ, gR):
         Q, R = ctx.saved_tensors
-        if gQ is None and gR is None:
-            return None
-        b = torch.zeros_like(R)
-        if gR is not None:
-            b = b + gR @ R.mT
-        if gQ is not None:
-            b = b - Q.mT @ gQ
-        b = b.triu()
-        b = b + b.mT
-        b.diagonal().mul_(0.5)
-        b = Q @ b
-        if gQ is not None:
-            b = b + gQ
-        return torch.linalg.solve_triangular(R.mT, b, upper=False, left=False)
+        return qr_backward(Q, R, gQ, gR)
+
+
+def qr_backward(Q, R, gQ, gR):
+    """gA for A = Q R (reduced, m >= n) from the cotangents of Q and R (either may be None)."""
+    if gQ is None and gR is None:
+        return None
+    b = torch.zeros_like(R)
+    if gR is not None:
+        b = b + gR @ R.mT
+    if gQ is not None:
+        b = b - Q.mT @ gQ
+    b = b.triu()
+    b = b + b.mT
+    b.diagonal().mul_(0.5)
+    b = Q @ b
+    if gQ is not None:
+        b = b + gQ
+    return torch.linalg.solve_triangular(R.mT, b, upper=False, left=False)
 
 
 def supported(A):

@@ -167,3 +167,57 @@ def test_lengthscale_priors_match_torch_distributions():
     for i, (_, _, pr, val) in enumerate(pri):
         ref = torch.distributions.Normal(ps[i], ps[i] * pw[i]).log_prob(val)
         assert torch.allclose(pr.log_prob(val), ref)
+
+
+def test_training_input_check_is_remembered_per_tensor_version(monkeypatch):
+    """An equal copy of the training inputs is compared once (torch.equal is a host sync on device tensors); the verdict
+    is kept for that tensor object at that version, an in-place change brings the comparison -- and the error -- back."""
+    X, Y = _data()
+    m = _model(X, Y, 2)
+    m.train()
+    calls = []
+    real_equal = torch.equal
+    monkeypatch.setattr(torch, "equal", lambda a, b: (calls.append(1), real_equal(a, b))[1])
+    Xc = X.clone()
+    m(Xc); m(Xc); m(Xc)
+    assert len(calls) == 1
+    m(X)                                       # the training tensor itself: never compared
+    assert len(calls) == 1
+    Xc[0, 0] += 1.0                            # version bump -> compared again -> different now
+    with pytest.raises(RuntimeError, match="train on the training inputs"):
+        m(Xc)
+    assert len(calls) == 2
+    Xc[0, 0] -= 1.0
+    m(Xc)
+    assert len(calls) == 3
+
+
+@pytest.mark.parametrize("shape", [(6, 6), (7, 3)])
+def test_reduced_qr_backward_formula_matches_torch(shape):
+    """The closed form behind projectedlmc._qr.SmallQR.backward (the device kernel only provides Q and R) against
+    autograd through torch.linalg.qr, with both outputs, with R only and with Q only."""
+    from projectedlmc import _qr
+    g = torch.Generator().manual_seed(4)
+    A = torch.randn(*shape, generator=g)
+    cQ = torch.randn(*shape, generator=g)
+    cR = torch.randn(shape[1], shape[1], generator=g).triu()
+    for use_q, use_r in ((True, True), (False, True), (True, False)):
+        Ar = A.clone().requires_grad_()
+        Q, R = torch.linalg.qr(Ar)
+        loss = (Q * cQ).sum() * float(use_q) + (R * cR).sum() * float(use_r)
+        loss.backward()
+        got = _qr.qr_backward(Q.detach(), R.detach(), cQ if use_q else None, cR if use_r else None)
+        assert torch.allclose(got, Ar.grad, rtol=1e-10, atol=1e-12), (use_q, use_r)
+    assert _qr.qr_backward(Q.detach(), R.detach(), None, None) is None
+
+
+def test_deferred_pivot_check_context_restores_the_outer_one():
+    from projectedlmc import _engine
+    assert _engine.deferred_pivot_checks.current is None
+    with _engine.deferred_pivot_checks(1e-6) as outer:
+        assert _engine.deferred_pivot_checks.current is outer and outer.jitter == 1e-6
+        with _engine.deferred_pivot_checks() as inner:
+            assert _engine.deferred_pivot_checks.current is inner
+        assert _engine.deferred_pivot_checks.current is outer
+    assert _engine.deferred_pivot_checks.current is None
+    assert outer.failed() is False and outer.first_bad is None
