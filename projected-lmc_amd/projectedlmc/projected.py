@@ -182,7 +182,10 @@ class ProjectedGPModel(ExactGPModel):
     def project_data(self, data):
         """(q x n) projected observations (projected_lmc.py:1014-1021)."""
         Q, R, Q_orth = self.lmc_coefficients.QR()
-        out = torch.linalg.solve_triangular(R, Q.T @ data.T, upper=True)
+        QtY = Q.T @ data.T                                               # q x n
+        # ProjectedLMCmll needs |Y Q|_F^2 of the same Y and Q (scalar-B discarded-noise term, :1215): keep the product
+        object.__setattr__(self, "_QtY_cache", (Q, data, QtY) if self.training else None)
+        out = torch.linalg.solve_triangular(R, QtY, upper=True)
         if hasattr(self, "M"):
             out = out + self.projected_noise()[:, None] * self.M @ Q_orth.T @ data.T
         return out
@@ -387,7 +390,10 @@ class ProjectedLMCmll(ExactMarginalLogLikelihood):
             if model.log_B_tilde.numel() > 0:
                 lb = model.log_B_tilde
                 root_diag = lb / 2
-                self.proj_term_list[1] = -0.5 * torch.exp(-lb[0]) * (model.Y_squared_norm - (target @ Q).pow(2).sum()) / num_data
+                cached = getattr(model, "_QtY_cache", None)              # Q^T Y^T of project_data, same Q and Y
+                YQ = cached[2] if (cached is not None and cached[0] is Q and cached[1] is target) else target @ Q
+                object.__setattr__(model, "_QtY_cache", None)
+                self.proj_term_list[1] = -0.5 * torch.exp(-lb[0]) * (model.Y_squared_norm - YQ.pow(2).sum()) / num_data
             else:
                 self.proj_term_list[1] = 0.
                 root_diag = torch.zeros(1, dtype=target.dtype, device=target.device)
