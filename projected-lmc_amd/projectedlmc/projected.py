@@ -376,7 +376,8 @@ class ProjectedLMCmll(ExactMarginalLogLikelihood):
             hyper = _engine.prepare_hyper_grad(ell_s, osc, nz_s)
         proj_target = model.project_data(target)                         # q x n
         if exact:
-            diff = proj_target - latent_output.loc                       # the latent means are zero (ZeroMean enforced)
+            # the latent means are zero (ZeroMean is enforced at construction): nothing to subtract
+            diff = proj_target if isinstance(model.mean_module, _m.ZeroMean) else proj_target - latent_output.loc
             latent_res = _engine.exact_latent_log_prob(c.kind, c.x1, ell_s, osc, nz_s, sel(diff), hyper=hyper)
         else:
             latent_res = latent_output.log_prob(proj_target)
