@@ -17,3 +17,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+def pytest_collection_modifyitems(config, items):
+    """Without a GPU the gpu-marked tests are skipped (not failed): a bare `pytest tests` on a CPU box stays green.
+    On a GPU box nothing is skipped -- the hot path has no CPU fallback to hide behind."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP GPU visible (gpu-marked tests run on the MI355X box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
