@@ -191,11 +191,21 @@ __device__ __forceinline__ void tile_mainloop(Acc<T, MT, NT> &acc, const T *__re
 // final barrier; needs 64 x 132 elements).  All 256 threads must call it.
 // The C tile is read with raw buffer loads (descriptor on the tile, per-thread voffset fixed, row-chunk offset in
 // soffset: no vector instruction for addresses) in chunks of 2 x 16 bytes per thread, software-pipelined: the
-// first chunk is requested before the accumulators are staged, every later one of a half while the previous is
-// combined and stored -- an un-prefetched read-modify-write left the workgroup idle for two HBM round trips per
-// tile, ~10 % of a depth-1024 update tile.  (Requesting the second half's first chunk across the half boundary as
-// well produced wrong factors under the look-ahead at n = 8192, q = 8 and correct ones with PLMC_SERIAL=1; not
-// understood, so each half starts its own pipeline after its staging barrier.)
+// first chunk of the tile is requested before the accumulators are staged, every later one while the previous is
+// combined and stored, across the half boundary as well -- an un-prefetched read-modify-write left the workgroup
+// idle for two HBM round trips per tile, ~10 % of a depth-1024 update tile.
+//
+// STORES carry their row-chunk offset in the VECTOR offset (soffset = 0), never in an SGPR.  gfx950 needs one wait
+// state between a `buffer_store_dwordx4 ..., sN offen` and a VALU write to its first data register, or lanes 12-15 of
+// every 16-lane row store the NEW register value (tools/store_hazard_probe.hip: 61 456 marker dwords at 0 wait
+// states, 0 at 1; with an immediate soffset 2 wait states are needed).  hipcc's hazard recognizer
+// (GCNHazardRecognizer::createsVALUHazard) inserts those wait states only for MUBUF stores WITHOUT an SGPR soffset
+// and emits nothing for the SGPR form, so whether a kernel was correct depended on what the scheduler happened to
+// place behind the store: with the cross-half prefetch it placed `v_and_b32 v16, 0x80, v0` (the wave-row test of the
+// second staging pass) directly behind `buffer_store_dwordx4 v[16:19], ..., s15 offen` and every update kernel
+// produced tiles with wrong elements in columns 48/52/56/60 (+64) from row 48 on -- the "wrong factors under the
+// look-ahead" of round 1 ("Write-back hazard").  With soffset = 0 the compiler sees the hazard it knows
+// and pads it itself; tests/test_isa_hazards.py scans the built library for the unprotected pattern.
 enum { WB_STORE = 0, WB_ADD = 1, WB_SUB = 2, WB_STORE_NEG = 3 };   // C = acc | C += acc | C -= acc | C = -acc
 template <typename T, int MODE, int MT = 4>
 __device__ __forceinline__ void tile_writeback(const Acc<T, MT> &acc, T *Cg, int64_t ldc, T *smem) {
@@ -208,6 +218,7 @@ __device__ __forceinline__ void tile_writeback(const Acc<T, MT> &acc, T *Cg, int
   constexpr int NCH = 64 * CPR / NTHREADS;             // chunks per thread per half (8 fp32 / 16 fp64)
   constexpr int RSTEP = NTHREADS / CPR;                // rows between a thread's chunks (8 / 4)
   constexpr int CH = 2;                                // chunks per pipeline stage
+  constexpr int NHALF = MT / 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int row0 = tid / CPR, col0 = (tid % CPR) * EPV;
@@ -223,7 +234,7 @@ __device__ __forceinline__ void tile_writeback(const Acc<T, MT> &acc, T *Cg, int
   if (ADD) cload(0, 0, vcur);
   // MT = 4: two passes of 64 rows, pass h staged by the wave row wm == h; MT = 2: one pass, both wave rows stage
 #pragma unroll
-  for (int half = 0; half < MT / 2; ++half) {
+  for (int half = 0; half < NHALF; ++half) {
     if (half) __syncthreads();                         // previous half fully read back
     if (MT == 2 || wm == half) {
 #pragma unroll
@@ -236,18 +247,19 @@ __device__ __forceinline__ void tile_writeback(const Acc<T, MT> &acc, T *Cg, int
         }
     }
     __syncthreads();
-    if (ADD && half == 1) cload(1, 0, vcur);
 #pragma unroll
     for (int h0 = 0; h0 < NCH; h0 += CH) {
       if (ADD) {
         if (h0 + CH < NCH) cload(half, h0 + CH, vnext);
+        else if (half + 1 < NHALF) cload(half + 1, 0, vnext);          // across the half boundary
       }
 #pragma unroll
       for (int h = 0; h < CH; ++h) {
         const vec_t sv = *reinterpret_cast<const vec_t *>(smem + (row0 + (h0 + h) * RSTEP) * LDW + col0);
         const vec_t o = MODE == WB_ADD ? vcur[h] + sv : (MODE == WB_SUB ? vcur[h] - sv : (MODE == WB_STORE_NEG ? -sv : sv));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o), rC, voff,
-                                               (unsigned)(half * (64 / RSTEP) + h0 + h) * rstep, 0);
+        // row-chunk offset in voffset, soffset = 0: see the hazard note above
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o), rC,
+                                               voff + (unsigned)(half * (64 / RSTEP) + h0 + h) * rstep, 0, 0);
       }
 #pragma unroll
       for (int h = 0; h < CH; ++h) vcur[h] = vnext[h];

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplmc_hip.so")
+# PLMC_LIB: dev override (a variant build of the same library, tools/wb_race_probe.py); never a fallback
+LIB_PATH = os.environ.get("PLMC_LIB") or os.path.join(_HERE, "libplmc_hip.so")
 
 KIND = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3}
 

@@ -179,10 +179,50 @@ def test_sarcos_scale_single_latent_fp32(eng):
     torch.cuda.empty_cache()
 
 
-def test_sweep_is_deterministic_at_metric_shape(eng):
-    """The look-ahead runs the chain, the head and the tail updates of the sweep on different streams; every tile
-    still receives its updates in a fixed order, so repeated factorisations at the metric shape must agree bit for
-    bit (a race between the streams would show up here as a difference or as a non-PD report)."""
+@pytest.mark.parametrize("n,q,dtype", [(8192, 8, torch.float32), (8192, 2, torch.float32), (4096, 4, torch.float64)],
+                         ids=["metric-f32-q8-wsplit", "f32-q2-two-streams", "f64-q4"])
+def test_sweep_is_deterministic_and_schedule_independent(eng, n, q, dtype):
+    """The look-ahead runs the chain, the head and the tail updates of the sweep on two or three streams (three with
+    q >= 4: the inverse-factor columns get their own chain); every tile still receives its updates in a fixed order, so
+    (a) repeated factorisations must agree bit for bit over the WHOLE factor buffer (U, augmented column, W), and
+    (b) they must agree bit for bit with the one-stream schedule (PLMC_SERIAL=1).  A race between the streams, or a
+    store-data hazard in the tile write-back ("Write-back hazard": round 1's "wrong factors under the
+    look-ahead" was exactly that and showed up here as thousands of differing tiles), fails this test."""
+    import os
+    d = 8
+    g = torch.Generator().manual_seed(5)
+    X = (2 * torch.rand(n, d, generator=g, dtype=dtype) - 1).to(DEV)
+    y = torch.randn(q, n, generator=g, dtype=dtype).to(DEV)
+    ell = torch.linspace(0.4, 1.0, q, dtype=dtype)[:, None].expand(q, d).contiguous().to(DEV)
+    noise = torch.linspace(0.05, 0.5, q, dtype=dtype).to(DEV)
+    ws = eng.Workspace(n, q, 1, dtype, torch.device(DEV), True)
+    it = torch.int32 if dtype == torch.float32 else torch.int64
+
+    def factor():
+        eng.factorize("matern52", X, ell, None, noise, y.reshape(q, 1, n), ws)
+        torch.cuda.synchronize()
+        return ws.A.view(it).clone(), ws.logdet.clone(), ws.info.clone()
+
+    assert "PLMC_SERIAL" not in os.environ
+    os.environ["PLMC_SERIAL"] = "1"
+    try:
+        ref, ld_ref, info_ref = factor()
+    finally:
+        del os.environ["PLMC_SERIAL"]
+    assert not bool(info_ref.any()) and bool(torch.isfinite(ld_ref).all())
+    for rep in range(4):
+        A, ld, info = factor()
+        ndiff = int((A != ref).sum())
+        assert ndiff == 0, "run %d: %d elements of the factor buffer differ from the one-stream schedule" % (rep, ndiff)
+        assert torch.equal(ld, ld_ref) and torch.equal(info, info_ref)
+        del A
+    del ref, ws
+    torch.cuda.empty_cache()
+
+
+def test_training_step_is_deterministic_at_metric_shape(eng):
+    """Whole MLL + gradient evaluation (sweep, alpha, fused K^-1 + gradient kernel on its own stream) repeated at the
+    metric shape: log-probs and every gradient bit-identical."""
     n, d, q = 8192, 8, 8
     g = torch.Generator().manual_seed(5)
     X = (2 * torch.rand(n, d, generator=g) - 1).to(DEV)
