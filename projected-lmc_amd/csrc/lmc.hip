@@ -122,6 +122,13 @@ __host__ __device__ inline int lmc_nacc(int p, int q, int d) { return q * p * p 
 // addresses for every element) stay in per-lane registers and are flushed to the LDS accumulators once per latent;
 // with every lane adding to the same LDS words per element the fp64 LDS atomics serialised 64-fold.  The
 // (task, task) scatter of dB and dSigma stays on LDS atomics (different lanes hit different words).
+// The walk is three real loops (mt, nt, r): the 16 accumulator registers of one sub-tile row mt are parked in LDS
+// (each thread reads back only what it wrote, no barrier) so that (nt, r) are runtime indices, and the (data point,
+// task) of every row / column comes from LDS tables instead of integer divisions per element.  Round 1 unrolled
+// mt x nt around a select chain and spilled 148 / 288 / 492 bytes per lane in fp64 (the C2 kernel); this form needs
+// no scratch (profiles/r02_resource_usage.md).
+constexpr int LMC_PARK_ELEMS = 4 * NTHREADS * 4;      // parked accumulator slice, T elements
+constexpr int LMC_TABLE_INTS = 4 * NB;                // rowA, rowS, colB, colT
 template <typename T, int DCAP>
 __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_lmc_kinv_grad(int kind, const T *__restrict__ W, int64_t N_pad, int64_t ldw,
                                                              const T *__restrict__ alpha, const T *__restrict__ X,
@@ -147,54 +154,71 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_lmc_kinv_grad(i
   uintptr_t ap = (reinterpret_cast<uintptr_t>(aj + NB) + 7) & ~(uintptr_t)7;
   double *accs = reinterpret_cast<double *>(ap);
   double *gB = accs, *gL = gB + q * p * p, *gO = gL + q * d, *gS = gO + q;
+  T *park = reinterpret_cast<T *>(accs + nacc) + tid * 4;             // [4 nt][256 threads][4 r]
+  int *rowA = reinterpret_cast<int *>(reinterpret_cast<T *>(accs + nacc) + LMC_PARK_ELEMS);
+  int *rowS = rowA + NB, *colB = rowS + NB, *colT = colB + NB;
+  const int64_t N = (int64_t)n * p;
   if (tid < NB) {
     ai[tid] = alpha[ib * NB + tid];
     aj[tid] = alpha[jb * NB + tid];
+    const int64_t I = (int64_t)ib * NB + tid, J = (int64_t)jb * NB + tid;
+    rowA[tid] = I < N ? (int)(I / p) : -1;                            // data point (-1: padding) and task of the row
+    rowS[tid] = (int)(I % p);
+    colB[tid] = J < N ? (int)(J / p) : -1;
+    colT[tid] = (int)(J % p);
   }
   for (int e = tid; e < nacc; e += NTHREADS) accs[e] = 0.0;
   __syncthreads();
-  const int64_t N = (int64_t)n * p;
   const int ldu = d + 1;
+  const bool diag_tile = jb == ib;
 #pragma unroll 1
   for (int i = 0; i < q; ++i) {
     T gl[DCAP], go = T(0);
 #pragma unroll
     for (int k = 0; k < DCAP; ++k) gl[k] = T(0);
     const T os_i = t.os[i];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    const T *invl = t.invl + i * d;
+    const T *Bi = t.B + i * p * p;
 #pragma unroll 1
-      for (int r = 0; r < 4; ++r) {
-        const int row = tile_row<T>(wm, mt, lane, r);
-        const int64_t I = (int64_t)ib * NB + row;
-        const int a = (int)(I / p), s = (int)(I % p);
-        const T a_i = ai[row];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int col = tile_col(wn, nt, lane);
-          const int64_t J = (int64_t)jb * NB + col;
-          const auto &av = acc.v[mt][nt];
-          const T kin = r == 0 ? av[0] : (r == 1 ? av[1] : (r == 2 ? av[2] : av[3]));
-          if (I < N && J < N && J >= I) {
-            const int b = (int)(J / p), tt = (int)(J % p);
-            const T wij = (I == J ? T(1) : T(2)) * (a_i * aj[col] - kin);
+    for (int mt = 0; mt < 4; ++mt) {
+#define PLMC_PARK(M)                                                                                    \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) _Pragma("unroll") for (int r = 0; r < 4; ++r)         \
+      park[nt * NTHREADS * 4 + r] = acc.v[M][nt][r];
+      if (mt == 0) { PLMC_PARK(0) } else if (mt == 1) { PLMC_PARK(1) } else if (mt == 2) { PLMC_PARK(2) } else { PLMC_PARK(3) }
+#undef PLMC_PARK
+#pragma unroll 1
+      for (int nt = 0; nt < 4; ++nt) {
+        const int col = tile_col(wn, nt, lane);
+        const int b = colB[col], tt = colT[col];
+        const T a_j = aj[col];
+        const T *xjc = t.xj + col * ldu;
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+          const int row = tile_row<T>(wm, mt, lane, r);
+          const int a = rowA[row], s = rowS[row];
+          if (a >= 0 && b >= 0 && (!diag_tile || col >= row)) {
+            const T kin = park[nt * NTHREADS * 4 + r];
+            const T wij = ((diag_tile && col == row) ? T(1) : T(2)) * (ai[row] * a_j - kin);
             if (i == 0 && a == b) atomicAdd(&gS[s * p + tt], (double)wij);
-            T dfs[DCAP];
+            const T *xir = t.xi + row * ldu;
             T r2 = T(0);
 #pragma unroll
             for (int k = 0; k < DCAP; ++k) {
-              const T df = k < d ? (t.xi[row * ldu + k] - t.xj[col * ldu + k]) * t.invl[i * d + k] : T(0);
-              dfs[k] = df * df;
-              r2 += dfs[k];
+              const T df = k < d ? (xir[k] - xjc[k]) * invl[k] : T(0);
+              r2 += df * df;
             }
             T val, base;
             kern_value_base<T>(kind, r2, val, base);
-            const T bst = t.B[(i * p + s) * p + tt];
+            const T bst = Bi[s * p + tt];
             atomicAdd(&gB[(i * p + s) * p + tt], (double)(wij * os_i * val));
             go += wij * val * bst;
             const T c = a != b ? wij * os_i * bst * base : T(0);
+            // the differences are formed a second time instead of keeping DCAP squares alive across the kernel value
 #pragma unroll
-            for (int k = 0; k < DCAP; ++k) gl[k] += c * dfs[k];
+            for (int k = 0; k < DCAP; ++k) {
+              const T df = k < d ? (xir[k] - xjc[k]) * invl[k] : T(0);
+              gl[k] += c * (df * df);
+            }
           }
         }
       }
@@ -280,7 +304,8 @@ int lmc_kinv_grad_impl(int kind, const T *W, int64_t N_pad, int64_t ldw, const T
   PLMC_REQUIRE(n > 0 && p > 0 && q > 0 && d > 0 && d <= MAX_DIM, "bad sizes");
   PLMC_REQUIRE(N_pad == plmc_pad((int64_t)n * p) && ldw % NB == 0 && aligned16(W), "N_pad must be plmc_pad(n*p)");
   const int nacc = lmc_nacc(p, q, d);
-  size_t epi = (lmc_stage_elems<T>(p, q, d) + 2 * NB) * sizeof(T) + 8 + (size_t)nacc * sizeof(double);
+  size_t epi = (lmc_stage_elems<T>(p, q, d) + 2 * NB) * sizeof(T) + 8 + (size_t)nacc * sizeof(double) +
+               (size_t)LMC_PARK_ELEMS * sizeof(T) + (size_t)LMC_TABLE_INTS * sizeof(int);
   size_t smem = (size_t)tile_smem_elems<T>() * sizeof(T);
   if (epi > smem) smem = epi;
   PLMC_REQUIRE(smem <= 150 * 1024, "q*p*p too large for the LDS accumulators");

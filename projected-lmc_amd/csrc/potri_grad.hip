@@ -16,35 +16,41 @@ namespace plmc {
 
 constexpr int GP = MAX_DIM + 2;      // partial-sum slots per tile: d lengthscales, noise, outputscale
 
-// Gradient sums of an interior tile (strictly above the diagonal, no padded rows or columns, nothing stored): every
-// element is live and counts twice, so the loop has no per-element predicate; KIND is a compile-time constant; two
-// columns (accumulator sub-tiles nt = 2 np, 2 np + 1, 16 columns apart) go through packed arithmetic.
-//     g[k] += 2 os w base df_k^2,    g_os += 2 w val,    w = alpha_i alpha_j - Kinv_ij.
-// The loops are real loops (a fully unrolled body let the scheduler hoist every LDS read and spill): the 16
-// accumulator registers of one sub-tile row mt are parked in LDS -- each thread reads back only what it wrote, no
-// barrier -- so that (np, r) can be runtime indices.  LDS plan (T elements), all inside tile_smem_elems():
-//   ui  [128][DCAP + 4]        scaled inputs of the tile's rows (b128 reads, broadcast inside 16-lane groups)
-//   ujp [64][2 DCAP + 4]       column pairs (c, c + 16) interleaved per dimension: one b128 = two ready pairs
-//   ai  [128], ajp [64][2]     alpha of rows / column pairs
-//   accs[4][256][4]            the parked accumulator slice
+// ---- gradient epilogue for d <= 8 (DCAP in {4, 8}): the metric shape and every BASELINE config but the SARCOS one.
+// The 64 accumulator registers stay live through the whole epilogue, so at 4 waves per SIMD (128 registers) the
+// epilogue itself has to fit ~60: round 1's version kept 16 packed column pairs + 16 packed sums + 8 row values and
+// spilled 80 bytes per lane (WRITE_SIZE 3.4 GB per launch for 9 MB of output).  Here the packed pairs are two
+// DIMENSIONS of one element instead of two elements: 4 packed sums, 4 packed column values, 4 packed differences
+// (kept for the second use: no recomputation), one scalar transcendental per element -- the same number of vector
+// instructions per element, half the registers, no scratch (tools/resource_usage.py, profiles/r02_resource_usage.md).
+// The loops are real loops: the 16 accumulator registers of one sub-tile row mt are parked in LDS -- each thread reads
+// back only what it wrote, no barrier -- so that (nt, r) can be runtime indices.
+// LDS plan (T elements), all inside tile_smem_elems():
+//   ui [128][DCAP + 4], uj [128][DCAP + 4]   scaled inputs u = x / ell of the tile's rows / columns (0 beyond n and d)
+//   ai [128], aj [128]                       alpha of rows / columns
+//   accs[4 nt][256 threads][4 r]             the parked accumulator slice
 template <int DCAP> struct GradLds {
-  static constexpr int LDI = DCAP + 4, LDP = 2 * DCAP + 4;
-  static constexpr int UI = 0, UJP = UI + NB * LDI, AI = UJP + 64 * LDP, AJP = AI + NB, ACCS = AJP + 128, END = ACCS + 4 * NTHREADS * 4;
+  static constexpr int LDI = DCAP + 4;
+  static constexpr int UI = 0, UJ = UI + NB * LDI, AI = UJ + NB * LDI, AJ = AI + NB, ACCS = AJ + NB, END = ACCS + 4 * NTHREADS * 4;
 };
-// pair index and slot of tile column c
-__device__ __forceinline__ int col_pair(int c) { return (c >> 6) * 32 + ((c >> 5) & 1) * 16 + (c & 15); }
-__device__ __forceinline__ int col_slot(int c) { return (c >> 4) & 1; }
 
-template <typename T, int DCAP, int KIND>
-__device__ __forceinline__ void grad_tile_interior(const Acc<T> &acc, T *smem, T os, T (&g)[DCAP], T &g_os) {
+// INTERIOR: tile strictly above the diagonal, no padded rows or columns, nothing stored -- every element is live and
+// counts twice, no per-element predicate.  Otherwise (diagonal tiles, ragged edge, K^-1 or its diagonal wanted):
+//   weight 2 above the diagonal, 1 on it (where df = 0, so it adds nothing to the lengthscale sums), 0 below / outside n.
+//     g[k] += os sum_ij wt w base df_k^2,   g_os += sum wt w val,   g_noise += sum_ii w,   w = alpha_i alpha_j - Kinv_ij.
+template <typename T, int DCAP, int KIND, bool INTERIOR>
+__device__ __forceinline__ void grad_tile_small(const Acc<T> &acc, T *smem, T os, int ib, int jb, int n, int lat, int64_t n_pad,
+                                                T *Kinv, int64_t ldk, int64_t strideK, T *kinv_diag, T (&g)[DCAP],
+                                                T &g_noise, T &g_os) {
   typedef Pair<T> T2;
   typedef GradLds<DCAP> L;
+  constexpr int NP = DCAP / 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  T2 g2[DCAP];
+  T2 g2[NP];
 #pragma unroll
-  for (int k = 0; k < DCAP; ++k) g2[k] = T2{T(0), T(0)};
-  T2 gos2 = {T(0), T(0)};
+  for (int j = 0; j < NP; ++j) g2[j] = T2{T(0), T(0)};
+  T gos = T(0), gnz = T(0);
   T *accs = smem + L::ACCS + tid * 4;
 #pragma unroll 1
   for (int mt = 0; mt < 4; ++mt) {
@@ -54,46 +60,53 @@ __device__ __forceinline__ void grad_tile_interior(const Acc<T> &acc, T *smem, T
       accs[nt * NTHREADS * 4 + r] = acc.v[M][nt][r];
     if (mt == 0) { PLMC_PARK(0) } else if (mt == 1) { PLMC_PARK(1) } else if (mt == 2) { PLMC_PARK(2) } else { PLMC_PARK(3) }
 #undef PLMC_PARK
-    const T *uir = smem + L::UI + tile_row<T>(wm, mt, lane, 0) * L::LDI;
-    const T *air = smem + L::AI + tile_row<T>(wm, mt, lane, 0);
 #pragma unroll 1
-    for (int np = 0; np < 2; ++np) {
-      const int pr = wn * 32 + np * 16 + (lane & 15);
-      T2 u2[DCAP];
+    for (int nt = 0; nt < 4; ++nt) {
+      const int col = tile_col(wn, nt, lane);
+      const T *ujc = smem + L::UJ + col * L::LDI;
+      T2 u2[NP];
 #pragma unroll
-      for (int k = 0; k < DCAP; ++k) u2[k] = *reinterpret_cast<const T2 *>(smem + L::UJP + pr * L::LDP + 2 * k);
-      const T2 a2 = *reinterpret_cast<const T2 *>(smem + L::AJP + 2 * pr);
+      for (int j = 0; j < NP; ++j) u2[j] = *reinterpret_cast<const T2 *>(ujc + 2 * j);
+      const T a_j = smem[L::AJ + col];
+      const int gj = jb * NB + col;
 #pragma unroll 1
       for (int r = 0; r < 4; ++r) {
-        const T2 kin = {accs[(2 * np) * NTHREADS * 4 + r], accs[(2 * np + 1) * NTHREADS * 4 + r]};
-        const T2 w = air[r] * a2 - kin;
-        T xi[DCAP];
+        const int row = tile_row<T>(wm, mt, lane, r);
+        const T kin = accs[nt * NTHREADS * 4 + r];
+        const T *uir = smem + L::UI + row * L::LDI;
+        T2 df[NP];
+        T2 r2p = {T(0), T(0)};
 #pragma unroll
-        for (int k = 0; k < DCAP; ++k) xi[k] = uir[r * L::LDI + k];
-        // the differences are formed twice (distance, then gradient weights) instead of keeping d squared pairs
-        // alive across the transcendental part
-        T2 r2 = {T(0), T(0)};
-#pragma unroll
-        for (int k = 0; k < DCAP; ++k) {
-          const T2 df = xi[k] - u2[k];
-          r2 += df * df;
+        for (int j = 0; j < NP; ++j) {
+          df[j] = *reinterpret_cast<const T2 *>(uir + 2 * j) - u2[j];
+          r2p += df[j] * df[j];
         }
-        T2 val, base;
-        kern_value_base_pair<T>(KIND, r2, val, base);
-        const T2 c = w * base;
-#pragma unroll
-        for (int k = 0; k < DCAP; ++k) {
-          const T2 df = xi[k] - u2[k];
-          g2[k] += (c * df) * df;
+        T val, base;
+        kern_value_base_fast(KIND, r2p.x + r2p.y, val, base);
+        T w = smem[L::AI + row] * a_j - kin;
+        if (!INTERIOR) {
+          const int gi = ib * NB + row;
+          if (Kinv && gj >= gi) Kinv[(int64_t)lat * strideK + (int64_t)gi * ldk + gj] = kin;
+          if (kinv_diag && gi == gj) kinv_diag[(int64_t)lat * n_pad + gi] = kin;
+          const bool live = gi < n && gj < n && gj >= gi;
+          if (live && gi == gj) gnz += w;
+          w = live ? (gj > gi ? T(2) * w : w) : T(0);
         }
-        gos2 += w * val;
+        gos += w * val;
+        const T c = w * base;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) g2[j] += (c * df[j]) * df[j];
       }
     }
   }
-  const T os2 = T(2) * os;
+  const T sc = INTERIOR ? T(2) * os : os;
 #pragma unroll
-  for (int k = 0; k < DCAP; ++k) g[k] += os2 * (g2[k].x + g2[k].y);
-  g_os += T(2) * (gos2.x + gos2.y);
+  for (int j = 0; j < NP; ++j) {
+    g[2 * j] += sc * g2[j].x;
+    g[2 * j + 1] += sc * g2[j].y;
+  }
+  g_os += INTERIOR ? T(2) * gos : gos;
+  g_noise += gnz;
 }
 
 // occupancy floor: fp32 with up to 8 input dimensions fits 128 registers (4 waves per SIMD, as the update kernels)
@@ -131,40 +144,6 @@ __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const T *el = ell + (int64_t)lat * d;
-  constexpr bool FAST = sizeof(T) == 4 && GradLds<DCAP>::END <= tile_smem_elems<T>();
-  const bool interior = FAST && ib < jb && (jb + 1) * NB <= n && !Kinv && !kinv_diag && plain != 5;
-  const int ldu = d + 1;
-  T *ui = smem;                        // general path: [128][ldu]
-  T *uj = ui + NB * ldu;               // [128][ldu]
-  T *ai = uj + NB * ldu;               // [128]
-  T *aj = ai + NB;                     // [128]
-  if (interior) {                      // unused dimensions are staged as zeros (they add 0 to every distance)
-    typedef GradLds<DCAP> L;
-    for (int e = tid; e < NB * DCAP; e += NTHREADS) {
-      const int r = e / DCAP, k = e % DCAP;
-      const T inv = k < d ? T(1) / el[k] : T(0);
-      smem[L::UI + r * L::LDI + k] = k < d ? X[(int64_t)(ib * NB + r) * d + k] * inv : T(0);
-      smem[L::UJP + col_pair(r) * L::LDP + 2 * k + col_slot(r)] = k < d ? X[(int64_t)(jb * NB + r) * d + k] * inv : T(0);
-    }
-    if (tid < NB) {
-      smem[L::AI + tid] = alpha[(int64_t)lat * n_pad + ib * NB + tid];
-      smem[L::AJP + 2 * col_pair(tid) + col_slot(tid)] = alpha[(int64_t)lat * n_pad + jb * NB + tid];
-    }
-  } else {
-    for (int e = tid; e < NB * d; e += NTHREADS) {
-      int r = e / d, k = e % d;
-      int gi = ib * NB + r, gj = jb * NB + r;
-      T inv = T(1) / el[k];
-      ui[r * ldu + k] = gi < n ? X[(int64_t)gi * d + k] * inv : T(0);
-      uj[r * ldu + k] = gj < n ? X[(int64_t)gj * d + k] * inv : T(0);
-    }
-    if (tid < NB) {
-      ai[tid] = alpha[(int64_t)lat * n_pad + ib * NB + tid];
-      aj[tid] = alpha[(int64_t)lat * n_pad + jb * NB + tid];
-    }
-  }
-  __syncthreads();
-
   const T os = oscale ? oscale[lat] : T(1);
   // per-lane partial sums over the lane's 64 tile elements stay in T (fp32 on the fp32 path: 64 terms,
   // relative error ~4e-6, far inside the fp32 gradient tolerance); everything across lanes, waves and
@@ -174,19 +153,56 @@ __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad
   for (int k = 0; k < DCAP; ++k) g[k] = T(0);
   T g_noise = T(0), g_os = T(0);
 
-  if constexpr (FAST) {
-    if (interior) {
-      if (kind == K_RBF) grad_tile_interior<T, DCAP, K_RBF>(acc, smem, os, g, g_os);
-      else if (kind == K_MATERN12) grad_tile_interior<T, DCAP, K_MATERN12>(acc, smem, os, g, g_os);
-      else if (kind == K_MATERN32) grad_tile_interior<T, DCAP, K_MATERN32>(acc, smem, os, g, g_os);
-      else grad_tile_interior<T, DCAP, K_MATERN52>(acc, smem, os, g, g_os);
+  if constexpr (DCAP <= 8) {
+    typedef GradLds<DCAP> L;
+    static_assert(L::END <= tile_smem_elems<T>(), "gradient epilogue LDS plan");
+    for (int e = tid; e < NB * DCAP; e += NTHREADS) {     // unused dimensions and rows beyond n are staged as zeros
+      const int r = e / DCAP, k = e % DCAP;
+      const int gi = ib * NB + r, gj = jb * NB + r;
+      const T inv = k < d ? T(1) / el[k] : T(0);
+      smem[L::UI + r * L::LDI + k] = (k < d && gi < n) ? X[(int64_t)gi * d + k] * inv : T(0);
+      smem[L::UJ + r * L::LDI + k] = (k < d && gj < n) ? X[(int64_t)gj * d + k] * inv : T(0);
     }
+    if (tid < NB) {
+      smem[L::AI + tid] = alpha[(int64_t)lat * n_pad + ib * NB + tid];
+      smem[L::AJ + tid] = alpha[(int64_t)lat * n_pad + jb * NB + tid];
+    }
+    __syncthreads();
+    const bool interior = ib < jb && (jb + 1) * NB <= n && !Kinv && !kinv_diag && plain != 5;
+#define PLMC_GRAD_TILE(KIND, INT) \
+  grad_tile_small<T, DCAP, KIND, INT>(acc, smem, os, ib, jb, n, lat, n_pad, Kinv, ldk, strideK, kinv_diag, g, g_noise, g_os)
+    if (interior) {
+      if (kind == K_RBF) PLMC_GRAD_TILE(K_RBF, true);
+      else if (kind == K_MATERN12) PLMC_GRAD_TILE(K_MATERN12, true);
+      else if (kind == K_MATERN32) PLMC_GRAD_TILE(K_MATERN32, true);
+      else PLMC_GRAD_TILE(K_MATERN52, true);
+    } else {
+      if (kind == K_RBF) PLMC_GRAD_TILE(K_RBF, false);
+      else if (kind == K_MATERN12) PLMC_GRAD_TILE(K_MATERN12, false);
+      else if (kind == K_MATERN32) PLMC_GRAD_TILE(K_MATERN32, false);
+      else PLMC_GRAD_TILE(K_MATERN52, false);
+    }
+#undef PLMC_GRAD_TILE
+  } else {
+  // d > 8: general tile code.  mt / nt are unrolled (static accumulator indices); the register r inside an MFMA tile
+  // is picked with a select chain -- a runtime-indexed accumulator would be demoted to scratch memory.
+  const int ldu = d + 1;
+  T *ui = smem;                        // [128][ldu]
+  T *uj = ui + NB * ldu;               // [128][ldu]
+  T *ai = uj + NB * ldu;               // [128]
+  T *aj = ai + NB;                     // [128]
+  for (int e = tid; e < NB * d; e += NTHREADS) {
+    int r = e / d, k = e % d;
+    int gi = ib * NB + r, gj = jb * NB + r;
+    T inv = T(1) / el[k];
+    ui[r * ldu + k] = gi < n ? X[(int64_t)gi * d + k] * inv : T(0);
+    uj[r * ldu + k] = gj < n ? X[(int64_t)gj * d + k] * inv : T(0);
   }
-  if (!interior) {
-  // general tile (diagonal, ragged edge, or K^-1 wanted in HBM).
-  // mt / nt are unrolled (static accumulator indices); the register r inside an MFMA tile is picked
-  // with a select chain -- a runtime-indexed accumulator would be demoted to scratch memory, and a
-  // kernel that needs scratch loses most of its occupancy.
+  if (tid < NB) {
+    ai[tid] = alpha[(int64_t)lat * n_pad + ib * NB + tid];
+    aj[tid] = alpha[(int64_t)lat * n_pad + jb * NB + tid];
+  }
+  __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll 1

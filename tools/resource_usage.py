@@ -53,7 +53,7 @@ def main():
             bad += sc > 0
             lines.append("| %s | `%s` | %s | %s | %s | %s | %s | %s |" % (
                 os.path.basename(f), r["pretty"], r.get("VGPRs", "?"), r.get("AGPRs", "?"), sc,
-                r.get("Occupancy [waves/SIMD]", "?"), r.get("SGPRs", "?"), r.get("LDS Size [bytes/block]", "?")))
+                r.get("Occupancy [waves/SIMD]", "?"), r.get("TotalSGPRs", "?"), r.get("LDS Size [bytes/block]", "?")))
     text = "\n".join(lines) + "\n\nkernels with scratch: %d\n" % bad
     if a.md:
         with open(a.md, "w") as fh:
