@@ -311,17 +311,18 @@ __global__ __launch_bounds__(NTHREADS) void k_logdet(const T *__restrict__ A, in
   if (tid == 0) { logdet[lat] = red[0]; info[lat] = redb[0] == 0x7fffffff ? 0 : redb[0]; }
 }
 
-// Zero the tiles of the diagonal-block outputs that k_diag never writes: Vd tiles (a, b) with a > b and
-// W_kk tiles (b, a) above the diagonal (16 x 16 tiles of every 128 x 128 diagonal block).  grid (m, q).
+// Zero the tiles of the diagonal-block outputs that k_diag never writes: Vd tiles (a, b) with a > b (blocks
+// kb < nvd) and W_kk tiles (b, a) above the diagonal (16 x 16 tiles of the diagonal blocks kb < nwd of a matrix with
+// leading dimension ldw, one block every wdiag_step elements).  grid (max(nvd, nwd), q).
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_zero_diag_out(T *__restrict__ Vd, int64_t strideV, T *Wd, int64_t ldw,
-                                                             int64_t strideW, int64_t wdiag_step) {
+__global__ __launch_bounds__(NTHREADS) void k_zero_diag_out(T *__restrict__ Vd, int64_t strideV, int nvd, T *Wd, int64_t ldw,
+                                                             int64_t strideW, int64_t wdiag_step, int nwd) {
   const int kb = blockIdx.x, lat = blockIdx.y;
-  T *vd = Vd + (int64_t)lat * strideV + (int64_t)kb * NB * NB;
-  T *wo = Wd ? Wd + (int64_t)lat * strideW + (int64_t)kb * wdiag_step : nullptr;
+  T *vd = kb < nvd ? Vd + (int64_t)lat * strideV + (int64_t)kb * NB * NB : nullptr;
+  T *wo = (Wd && kb < nwd) ? Wd + (int64_t)lat * strideW + (int64_t)kb * wdiag_step : nullptr;
   for (int e = threadIdx.x; e < NB * NB; e += NTHREADS) {
     const int i = e >> 7, j = e & 127;
-    if ((i >> 4) > (j >> 4)) vd[e] = T(0);
+    if (vd && (i >> 4) > (j >> 4)) vd[e] = T(0);
     if (wo && (j >> 4) > (i >> 4)) wo[(int64_t)i * ldw + j] = T(0);
   }
 }

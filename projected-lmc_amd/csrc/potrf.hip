@@ -8,14 +8,18 @@
 //
 // The buffer is [ Khat | rhs | I ]: everything right of the square part is "just more columns" of the
 // same elimination, so  U^-T y  (forward solve), U^-T K*^T (prediction) and W = U^-T I (inverse factor)
-// all fall out of one sweep built from two MFMA tile kernels:
-//     k_panel  : row panel  P <- V_rr^T P                      (in place, K = 128)
-//     k_update : C[i][j]  -= sum_k P[k][i] P[k][j]              (upper tiles of U, aug, live tiles of W)
-// Block rows are processed in GROUPS of g (two-level blocking): inside a group each row is brought up to
-// date with the rows of the group done so far (depth <= 128 (g - 1)); the large trailing update then runs
-// once per group with depth 128 g, which divides the read-modify-write traffic of the trailing matrix by
-// g.  The latency-bound chain of the next group runs beside that update on a helper stream (potrf_impl).
+// all fall out of one sweep.  Block rows are processed in GROUPS of G <= 8 (two-level blocking):
+//   1. the latency-bound CHAIN only touches the group's G x G diagonal triangle of 128-blocks: factor + invert the
+//      diagonal block (k_diag), solve / update the <= G - 1 tiles right of it (k_panel, k_update), and build the
+//      group's inverse triangle Wgg = Ugg^-T the same way in a scratch buffer (Wg);
+//   2. k_vtrans turns Wgg into its transpose Vgg = Ugg^-1 (K-major, what the TN tile engine wants);
+//   3. the GROUP PANEL (k_gpanel) then solves the whole block row of the group against the triangle as ONE product
+//      P = Vgg^T A over all columns right of the group, the augmented columns and the inverse-factor columns left
+//      of the group -- the same flops as G row-by-row panel solves and within-group row updates, in one MFMA-bound
+//      launch instead of 2 G latency-bound ones;
+//   4. the trailing update C -= P^T P of depth 128 G (k_update) runs once per group.
 // Tiles of W are written (not accumulated) the first time they are touched, so W needs no memset.
+// The chain of the NEXT group runs beside the group panel / trailing update of the current one (potrf_impl).
 #include <stdlib.h>
 #include <vector>
 #include "api_common.hpp"
@@ -25,83 +29,165 @@
 
 namespace plmc {
 
-// Column-tile decoding shared by k_panel / k_update.  Tiles along grid.x are laid out as
-//   [ U block columns u0 .. m-1 | aug tiles (Taug) | W block columns 0 .. nW-1 ].
-struct ColMap {
-  int u0, nU, Taug, nW;
-  int64_t n_pad, wcol0;
+constexpr int GMAX = 8;                       // largest group (block rows)
+constexpr int LDG = GMAX * NB;                // leading dimension of the group scratch matrices (Wg, Vg)
+// per-latent scratch behind the m inverse diagonal blocks of Vd: Wg + two Vg (ping-pong), GMAX^2 blocks each
+constexpr int VD_EXTRA_BLOCKS = 3 * GMAX * GMAX;
+
+// Column-tile decoding shared by k_panel / k_update / k_gpanel.  Tiles along grid.x are laid out as
+//   [ U block columns u0 .. u0+nU-1 | aug tiles (Taug) | W block columns w0 .. w0+nW-1 ].
+// The W part has its own base / leading dimension / batch stride, indexed by ABSOLUTE (block row, block column):
+// either the inverse-factor columns of the factor buffer (W = A + wcol0, ldw = lda) or the group scratch Wg
+// (pointer pre-shifted by the group's first block so that absolute indices work).
+template <typename T> struct ColMap {
+  int u0, nU, Taug, w0, nW;
+  int64_t n_pad;
+  T *W;
+  int64_t ldw, strideW;
 };
 
 // Row panel solve P <- V_rr^T P for block row r.  grid (nU + Taug + nW, q, 4 / NT): NT = 2 splits every 128 x 128 tile
 // into two 64-COLUMN halves -- the solve is in place and every output row needs all 128 input rows of its column,
 // so only a column split keeps workgroups independent -- for launches that would not fill the CUs.
 template <typename T, int NT>
-__global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_panel(T *A, int64_t lda, int64_t strideA, int r, ColMap cm,
+__global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_panel(T *A, int64_t lda, int64_t strideA, int r, ColMap<T> cm,
                                                      const T *__restrict__ Vd, int64_t strideV) {
   __builtin_amdgcn_s_setprio(3);       // chain kernel: ahead of the concurrently running trailing update
   __shared__ __align__(16) T smem[tile_smem_elems<T>()];
   const int lat = blockIdx.y, t = blockIdx.x;
-  int64_t col0;
-  if (t < cm.nU) col0 = (int64_t)(cm.u0 + t) * NB;
-  else if (t < cm.nU + cm.Taug) col0 = cm.n_pad + (int64_t)(t - cm.nU) * NB;
-  else col0 = cm.wcol0 + (int64_t)(t - cm.nU - cm.Taug) * NB;
-  T *P = A + (int64_t)lat * strideA + (int64_t)r * NB * lda + col0 + (int)blockIdx.z * (32 * NT);
+  T *P;
+  int64_t ldp = lda;
+  if (t < cm.nU) P = A + (int64_t)lat * strideA + (int64_t)r * NB * lda + (int64_t)(cm.u0 + t) * NB;
+  else if (t < cm.nU + cm.Taug) P = A + (int64_t)lat * strideA + (int64_t)r * NB * lda + cm.n_pad + (int64_t)(t - cm.nU) * NB;
+  else {
+    ldp = cm.ldw;
+    P = cm.W + (int64_t)lat * cm.strideW + (int64_t)r * NB * ldp + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
+  }
+  P += (int)blockIdx.z * (32 * NT);
   const T *V = Vd + (int64_t)lat * strideV + (int64_t)r * NB * NB;
   Acc<T, 4, NT> acc;
   acc.zero();
-  tile_mainloop<T, false, false, 4, NT>(acc, V, NB, P, lda, NB, smem);
-  tile_store<T, 4, NT>(acc, P, lda);
+  tile_mainloop<T, false, false, 4, NT>(acc, V, NB, P, ldp, NB, smem);
+  tile_store<T, 4, NT>(acc, P, ldp);
 }
 
 // Rank-(128 g) update of block rows [ib0, ib0 + nrows) with the panel rows of block rows
 // r_lo..r_hi:  C[i][j] -= sum_{k in panel} P[k][i] P[k][j].   grid (nU + Taug + nW, nrows, q).
-//   U columns : tiles with jb >= ib (upper), read-modify-write.
+//   U columns : tiles with jb >= ib (upper), read-modify-write; tiles with ib < skip_ib && jb < skip_jb are left to
+//               another launch (the look-ahead updates the next group's triangle on the chain stream).
 //   aug       : read-modify-write.
 //   W column cb < r_lo : read-modify-write, full panel depth;
-//            cb == r_lo : first touch -> plain store, full depth;
-//            cb == r_hi (> r_lo): first touch, only the rows of block r_hi contribute (W[r_lo][r_hi] = 0).
-// ROLE 0 = the big trailing ("tail") update, 1 = the single-row launches inside a group (latency-critical:
-// raised wave priority), 2 = the "head" rows the next group needs.  Separate symbols keep the three launch
+//            cb >= r_lo : first touch -> plain store; only the panel rows cb..r_hi contribute (W[r][cb] = 0 for r < cb).
+// ROLE 0 = the big trailing ("tail") update, 1 = the single-row launches inside a group's triangle (latency-critical:
+// raised wave priority), 2 = the look-ahead updates of the next group's triangle.  Separate symbols keep the launch
 // shapes apart in kernel traces and counter passes.
 // MT = 2 splits every 128 x 128 tile into two 64-row halves (grid.y doubled): twice the workgroups for the chain's
-// launches when full tiles would not fill the CUs (single-latent shards).  (k_panel cannot be split this way: it
-// works in place and every output row needs all 128 input rows of its column.)
+// launches when full tiles would not fill the CUs.  (k_panel cannot be split this way: it works in place and every
+// output row needs all 128 input rows of its column.)
 template <typename T, int ROLE, int MT = 4>
 __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, int64_t lda, int64_t strideA, int ib0, int r_lo, int r_hi,
-                                                      ColMap cm) {
+                                                      ColMap<T> cm, int skip_ib, int skip_jb) {
   if (ROLE == 1) __builtin_amdgcn_s_setprio(3);
-  if (ROLE == 2) __builtin_amdgcn_s_setprio(2);       // head rows: the next chain waits for them
+  if (ROLE == 2) __builtin_amdgcn_s_setprio(2);       // look-ahead rows: the next chain waits for them
   // plain row-major tile order: an XCD-dealt super-block order (xcd_tri_decode, gemm_core.hpp) was 3 % faster for a
-  // launch that has the GPU to itself and 25 % slower in the sweep, where launches from three streams
+  // launch that has the GPU to itself and 25 % slower in the sweep, where launches from several streams
   // interleave and "workgroup w lands on XCD w % 8" no longer holds
   constexpr int SPLIT = 4 / MT;                                      // half tiles per tile
   const int bx = blockIdx.x, ib = ib0 + (int)blockIdx.y / SPLIT, lat = blockIdx.z;
   const int h0 = ((int)blockIdx.y % SPLIT) * (32 * MT);             // first row of this half inside the block row
-  int64_t col0;
   int kr0 = r_lo * NB, depth = (r_hi - r_lo + 1) * NB;
   bool first = false;
+  T *Al = A + (int64_t)lat * strideA;
+  T *Cb = Al;                          // base / leading dimension of the C tile and of the B operand
+  int64_t ldc = lda, col0;
   if (bx < cm.nU) {
     const int jb = cm.u0 + bx;
-    if (jb < ib) return;
+    if (jb < ib || (ib < skip_ib && jb < skip_jb)) return;
     col0 = (int64_t)jb * NB;
   } else if (bx < cm.nU + cm.Taug) {
     col0 = cm.n_pad + (int64_t)(bx - cm.nU) * NB;
   } else {
-    const int cb = bx - cm.nU - cm.Taug;
-    col0 = cm.wcol0 + (int64_t)cb * NB;
+    const int cb = cm.w0 + bx - cm.nU - cm.Taug;
+    Cb = cm.W + (int64_t)lat * cm.strideW;
+    ldc = cm.ldw;
+    col0 = (int64_t)cb * NB;
     // columns that start inside the current group: W[r][cb] = 0 for r < cb, so only panel rows
     // cb..r_hi contribute, and this is the first time the tile is touched -> plain store
     if (cb >= r_lo) { first = true; kr0 = cb * NB; depth = (r_hi - cb + 1) * NB; }
   }
   __shared__ __align__(16) T smem[tile_smem_elems<T>()];
-  T *Al = A + (int64_t)lat * strideA;
-  const T *Prow = Al + (int64_t)kr0 * lda;
   Acc<T, MT> acc;
   acc.zero();
-  tile_mainloop<T, false, false, MT>(acc, Prow + (int64_t)ib * NB + h0, lda, Prow + col0, lda, depth, smem);
-  T *C = Al + ((int64_t)ib * NB + h0) * lda + col0;
-  if (first) tile_writeback<T, WB_STORE_NEG, MT>(acc, C, lda, smem);   // C = -P^T P (first touch of a W tile)
-  else tile_writeback<T, WB_SUB, MT>(acc, C, lda, smem);               // C -= P^T P
+  tile_mainloop<T, false, false, MT>(acc, Al + (int64_t)kr0 * lda + (int64_t)ib * NB + h0, lda, Cb + (int64_t)kr0 * ldc + col0, ldc,
+                                     depth, smem);
+  T *C = Cb + ((int64_t)ib * NB + h0) * ldc + col0;
+  if (first) tile_writeback<T, WB_STORE_NEG, MT>(acc, C, ldc, smem);   // C = -P^T P (first touch of a W tile)
+  else tile_writeback<T, WB_SUB, MT>(acc, C, ldc, smem);               // C -= P^T P
+}
+
+// Group panel: for one 128-column strip (grid.x, decoded by ColMap) of the group's block rows g0 .. g0+G-1,
+//     P[i] = sum_{k <= i} Vgg[k][i]^T A[k]      (i = G-1 ... 0, in place)
+// with Vgg = Ugg^-1 (upper, K-major, leading dimension ldv) -- U^-T applied to the whole block row as G products of
+// depth 128 (i + 1).  Going DOWN in i makes the in-place update safe inside the workgroup that owns the strip: row i
+// is only read by the products of rows >= i, which are done when it is overwritten.  grid (tiles, q, 4 / NT).
+template <typename T, int NT>
+__global__ __launch_bounds__(NTHREADS, (sizeof(T) == 8 ? 2 : 4)) void k_gpanel(T *A, int64_t lda, int64_t strideA, int g0, int G, ColMap<T> cm,
+                                                      const T *__restrict__ Vg, int64_t ldv, int64_t strideVg, int prio) {
+  if (prio) __builtin_amdgcn_s_setprio(2);
+  __shared__ __align__(16) T smem[tile_smem_elems<T>()];
+  const int lat = blockIdx.y, t = blockIdx.x;
+  T *S;
+  int64_t lds = lda;
+  if (t < cm.nU) S = A + (int64_t)lat * strideA + (int64_t)g0 * NB * lda + (int64_t)(cm.u0 + t) * NB;
+  else if (t < cm.nU + cm.Taug) S = A + (int64_t)lat * strideA + (int64_t)g0 * NB * lda + cm.n_pad + (int64_t)(t - cm.nU) * NB;
+  else {
+    lds = cm.ldw;
+    S = cm.W + (int64_t)lat * cm.strideW + (int64_t)g0 * NB * lds + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
+  }
+  S += (int)blockIdx.z * (32 * NT);
+  const T *V = Vg + (int64_t)lat * strideVg;
+#pragma unroll 1
+  for (int i = G - 1; i >= 0; --i) {
+    Acc<T, 4, NT> acc;
+    acc.zero();
+    tile_mainloop<T, false, false, 4, NT>(acc, V + (int64_t)i * NB, ldv, S, lds, (i + 1) * NB, smem);
+    if constexpr (NT == 4) {
+      tile_writeback<T, WB_STORE, 4>(acc, S + (int64_t)i * NB * lds, lds, smem);
+      __syncthreads();                 // staging buffer free before the next product refills it
+    } else {
+      tile_store<T, 4, NT>(acc, S + (int64_t)i * NB * lds, lds);
+    }
+  }
+}
+
+// Transpose of the group's inverse triangle: Vg[k][i] = Wg[i][k]^T for block pairs k <= i < G (Vg = Ugg^-1, upper,
+// K-major for the tile engine) and, when the inverse factor is wanted, the copy of Wg[i][k] into the factor buffer's
+// W columns (block row g0 + i, block column g0 + k).  grid (G (G + 1) / 2, q), 32 x 32 sub-tiles through LDS.
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, int64_t strideG, T *__restrict__ Vg, int G, T *Wout,
+                                                     int64_t ldw, int64_t strideW) {
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ T tile[32][33];
+  const int lat = blockIdx.y;
+  int i = 0, k = (int)blockIdx.x;                    // blockIdx.x enumerates (i, k <= i) row by row
+  while (k > i) { k -= i + 1; ++i; }
+  const T *src = Wg + (int64_t)lat * strideG + (int64_t)i * NB * LDG + (int64_t)k * NB;
+  T *dst = Vg + (int64_t)lat * strideG + (int64_t)k * NB * LDG + (int64_t)i * NB;
+  T *wo = Wout ? Wout + (int64_t)lat * strideW + (int64_t)i * NB * ldw + (int64_t)k * NB : nullptr;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  for (int bi = 0; bi < NB; bi += 32)
+    for (int bk = 0; bk < NB; bk += 32) {
+#pragma unroll
+      for (int r = 0; r < 32; r += 8) {
+        const T v = src[(int64_t)(bi + ty + r) * LDG + bk + tx];
+        tile[ty + r][tx] = v;
+        if (wo) wo[(int64_t)(bi + ty + r) * ldw + bk + tx] = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 32; r += 8) dst[(int64_t)(bk + ty + r) * LDG + bi + tx] = tile[tx][ty + r];
+      __syncthreads();
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -189,62 +275,97 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const hipStream_t st = (hipStream_t)stream;
   const int m = (int)(n_pad / NB);
   const int Taug = (int)(naug_pad / NB);
-  const int64_t strideV = (int64_t)m * NB * NB;
+  const int64_t strideV = plmc_vd_blocks(n_pad) * (int64_t)NB * NB;      // per latent: m diagonal inverses + group scratch
   const int64_t wcol0 = n_pad + naug_pad;
   const double nb = (double)NB, nb3 = nb * nb * nb, esz = sizeof(T);
+  // group scratch of latent 0 (batch stride strideV): the inverse triangle Wg and two transposed copies (ping-pong:
+  // the group panel of one group may still read its copy while the chain of the next group writes the other)
+  T *const Wg = Vd + (int64_t)m * NB * NB;
+  T *const Vg2[2] = {Wg + (int64_t)GMAX * NB * LDG, Wg + 2 * (int64_t)GMAX * NB * LDG};
+  T *const WA = with_inverse ? A + wcol0 : (T *)nullptr;                // inverse-factor columns of the factor buffer
 
-  auto diag = [&](int r, hipStream_t st) {
-    ProfScope ps(PK_DIAG, st, q * (2.0 / 3.0) * nb3, q * 3.0 * nb * nb * esz);
-    T *wout = with_inverse ? A + (int64_t)r * NB * lda + wcol0 + (int64_t)r * NB : (T *)nullptr;
-    hipLaunchKernelGGL((k_diag<T>), dim3(q), dim3(DIAG_NT), 0, st, A, lda, strideA, r, Vd, strideV, wout, lda, strideA);
+  // env knobs are dev aids; read once per process (getenv is not free and the values never change under a run)
+  struct Knobs { double hthr; int grp; bool serial; };
+  static const Knobs knobs = [] {
+    Knobs k;
+    const char *h = getenv("PLMC_HALF_TILES");          // 0 = never, 1 = always, N > 1 = tile-count threshold
+    k.hthr = h ? (atoi(h) == 1 ? 1e30 : (double)atoi(h)) : 640.0;
+    const char *g = getenv("PLMC_GRP");                 // fixed group size (1..GMAX)
+    k.grp = g ? atoi(g) : 0;
+    k.serial = getenv("PLMC_SERIAL_ALWAYS") != nullptr; // one stream for every sweep of the process
+    return k;
+  }();
+  const double hthr = knobs.hthr;
+  const bool serial = knobs.serial || getenv("PLMC_SERIAL") != nullptr;   // PLMC_SERIAL: per call (tests toggle it)
+
+  auto diag = [&](int r, int g0, hipStream_t s) {
+    ProfScope ps(PK_DIAG, s, q * (2.0 / 3.0) * nb3, q * 3.0 * nb * nb * esz);
+    T *wout = Wg + (int64_t)(r - g0) * NB * LDG + (int64_t)(r - g0) * NB;
+    hipLaunchKernelGGL((k_diag<T>), dim3(q), dim3(DIAG_NT), 0, s, A, lda, strideA, r, Vd, strideV, wout, (int64_t)LDG, strideV);
   };
-  // launches with few tiles run on half tiles (dev knob PLMC_HALF_TILES: 0 = never, 1 = always, N > 1 = tile-count
-  // threshold); read once per sweep, not per launch
-  const char *henv = getenv("PLMC_HALF_TILES");
-  const double hthr = henv ? (atoi(henv) == 1 ? 1e30 : (double)atoi(henv)) : 640.0;
-  // part: 0 = every column of the row, 1 = U + augmented columns only, 2 = inverse-factor (W) columns only
-  auto panel = [&](int r, hipStream_t st, int part = 0) {
-    ColMap cm{r + 1, part == 2 ? 0 : m - 1 - r, part == 2 ? 0 : Taug, (with_inverse && part != 1) ? r : 0, n_pad, wcol0};
+  // W part of a column map: the group scratch, shifted so that absolute block indices address it
+  auto cm_tri = [&](int g0, int u0, int nU, int w0, int nW) {
+    return ColMap<T>{u0, nU, 0, w0, nW, n_pad, Wg - (int64_t)g0 * NB * LDG - (int64_t)g0 * NB, (int64_t)LDG, strideV};
+  };
+  // ... or the factor buffer's own columns (aug + inverse factor)
+  auto cm_buf = [&](int u0, int nU, int taug, int w0, int nW) {
+    return ColMap<T>{u0, nU, taug, w0, WA ? nW : 0, n_pad, WA, lda, strideA};
+  };
+  auto panel = [&](int r, const ColMap<T> &cm, hipStream_t s) {
     const int nt = cm.nU + cm.Taug + cm.nW;
     if (nt == 0) return;
     // algorithmic: triangular solve of nt*NB columns with a 128 x 128 factor = nb^2 flops per column
-    ProfScope ps(PK_PANEL, st, q * (double)nt * nb3, q * 2.0 * nt * nb * nb * esz);
+    ProfScope ps(PK_PANEL, s, q * (double)nt * nb3, q * 2.0 * nt * nb * nb * esz);
     if ((double)nt * q <= hthr)
-      hipLaunchKernelGGL((k_panel<T, 2>), dim3(nt, q, 2), dim3(NTHREADS), 0, st, A, lda, strideA, r, cm, Vd, strideV);
+      hipLaunchKernelGGL((k_panel<T, 2>), dim3(nt, q, 2), dim3(NTHREADS), 0, s, A, lda, strideA, r, cm, Vd, strideV);
     else
-      hipLaunchKernelGGL((k_panel<T, 4>), dim3(nt, q, 1), dim3(NTHREADS), 0, st, A, lda, strideA, r, cm, Vd, strideV);
+      hipLaunchKernelGGL((k_panel<T, 4>), dim3(nt, q, 1), dim3(NTHREADS), 0, s, A, lda, strideA, r, cm, Vd, strideV);
   };
-  // cls: profiler class of the launch -- PK_TRAIL (the big trailing update), PK_TRAIL_HEAD (the rows the next
-  // group needs, on the chain stream), PK_TRAIL_ROW (single row inside a group)
-  auto update = [&](int ib0, int nrows, int r_lo, int r_hi, hipStream_t st, int cls, int part = 0) {
-    if (nrows <= 0) return;
-    ColMap cm{ib0, part == 2 ? 0 : m - ib0, part == 2 ? 0 : Taug, (with_inverse && part != 1) ? r_hi + 1 : 0, n_pad, wcol0};
-    if (cm.nU + cm.Taug + cm.nW == 0) return;
-    const double depth = (r_hi - r_lo + 1) * nb;
-    // algorithmic flops: symmetric rank-k update of the nrows block rows (upper tiles only) + rectangular parts
-    const double nr = (double)nrows;
-    const double tilesU = part == 2 ? 0.0 : nr * (cm.nU) - nr * (nr - 1) / 2.0;  // tiles jb >= ib
-    const double flopsU = part == 2 ? 0.0 : 2.0 * nb * nb * depth * (tilesU - nr / 2.0);   // diagonal tiles count half
-    const double tilesA = nr * cm.Taug;
-    double depthW = 0.0;                                                         // summed panel depth over W columns
-    for (int cb = 0; cb < cm.nW; ++cb) depthW += (cb >= r_lo ? (r_hi - cb + 1) : (r_hi - r_lo + 1)) * nb;
-    const double flopsR = 2.0 * nb * nb * nr * (depth * cm.Taug + depthW);
-    const int nfirst = cm.nW > 0 ? r_hi - r_lo + 1 : 0;                          // first-touch W columns: no read
-    const double bytes = (2.0 * (tilesU + tilesA + nr * cm.nW) - nr * nfirst) * nb * nb * esz;
-    ProfScope ps(cls, st, q * (flopsU + flopsR), q * bytes);
+  // cls: profiler class of the launch -- PK_TRAIL (the big trailing update), PK_TRAIL_HEAD (look-ahead updates of
+  // the next group's tiles on the chain stream), PK_TRAIL_ROW (single row inside a group's triangle)
+  auto update = [&](int ib0, int nrows, int r_lo, int r_hi, const ColMap<T> &cm, hipStream_t s, int cls, int skip_ib = 0,
+                    int skip_jb = 0) {
     const int Cn = cm.nU + cm.Taug + cm.nW;
-    // chain launches with few tiles (single-latent shards) run on 64-row half tiles: twice the workgroups
+    if (nrows <= 0 || Cn == 0) return;
+    const double depth = (r_hi - r_lo + 1) * nb, nr = (double)nrows;
+    // algorithmic flops: upper tiles of the U part (diagonal tiles count half), rectangular aug / W parts
+    double tilesU = 0.0, halfU = 0.0;
+    for (int i = 0; i < nrows; ++i)
+      for (int t = 0; t < cm.nU; ++t) {
+        const int ib = ib0 + i, jb = cm.u0 + t;
+        if (jb < ib || (ib < skip_ib && jb < skip_jb)) continue;
+        tilesU += 1.0;
+        if (jb == ib) halfU += 0.5;
+      }
+    double depthW = 0.0;
+    int nfirst = 0;
+    for (int c = 0; c < cm.nW; ++c) {
+      const int cb = cm.w0 + c;
+      depthW += (cb >= r_lo ? (r_hi - cb + 1) : (r_hi - r_lo + 1)) * nb;
+      nfirst += cb >= r_lo;
+    }
+    const double flops = 2.0 * nb * nb * (depth * (tilesU - halfU) + nr * (depth * cm.Taug + depthW));
+    const double bytes = (2.0 * (tilesU + nr * (cm.Taug + cm.nW)) - nr * nfirst) * nb * nb * esz;
+    ProfScope ps(cls, s, q * flops, q * bytes);
+    // launches with few tiles run on 64-row half tiles: twice the workgroups
     const bool half = cls != PK_TRAIL && (double)Cn * nrows * q <= hthr;
     const dim3 grid(Cn, half ? 2 * nrows : nrows, q);
-    if (cls == PK_TRAIL_ROW) {
-      if (half) hipLaunchKernelGGL((k_update<T, 1, 2>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
-      else hipLaunchKernelGGL((k_update<T, 1, 4>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
-    } else if (cls == PK_TRAIL_HEAD) {
-      if (half) hipLaunchKernelGGL((k_update<T, 2, 2>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
-      else hipLaunchKernelGGL((k_update<T, 2, 4>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
-    } else {
-      hipLaunchKernelGGL((k_update<T, 0, 4>), grid, dim3(NTHREADS), 0, st, A, lda, strideA, ib0, r_lo, r_hi, cm);
-    }
+#define PLMC_UPD(ROLE, MT) \
+  hipLaunchKernelGGL((k_update<T, ROLE, MT>), grid, dim3(NTHREADS), 0, s, A, lda, strideA, ib0, r_lo, r_hi, cm, skip_ib, skip_jb)
+    if (cls == PK_TRAIL_ROW) { if (half) PLMC_UPD(1, 2); else PLMC_UPD(1, 4); }
+    else if (cls == PK_TRAIL_HEAD) { if (half) PLMC_UPD(2, 2); else PLMC_UPD(2, 4); }
+    else PLMC_UPD(0, 4);
+#undef PLMC_UPD
+  };
+  auto gpanel = [&](int g0, int G, const ColMap<T> &cm, const T *Vg, hipStream_t s, int prio) {
+    const int nt = cm.nU + cm.Taug + cm.nW;
+    if (nt == 0) return;
+    const double prods = G * (G + 1) / 2.0;               // 128-deep tile products per column strip
+    ProfScope ps(PK_GPANEL, s, q * (double)nt * prods * 2.0 * nb3, q * (double)nt * (prods + G) * nb * nb * esz);
+    if ((double)nt * q <= hthr)
+      hipLaunchKernelGGL((k_gpanel<T, 2>), dim3(nt, q, 2), dim3(NTHREADS), 0, s, A, lda, strideA, g0, G, cm, Vg, (int64_t)LDG, strideV, prio);
+    else
+      hipLaunchKernelGGL((k_gpanel<T, 4>), dim3(nt, q, 1), dim3(NTHREADS), 0, s, A, lda, strideA, g0, G, cm, Vg, (int64_t)LDG, strideV, prio);
   };
 
   // whole-sweep bracket on the caller's stream (the per-kernel records of overlapped kernels add up to
@@ -252,159 +373,90 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const double npd = (double)n_pad;
   ProfScope whole(PK_SWEEP, st, q * (with_inverse ? 2.0 : 1.0) * npd * npd * npd / 3.0, 0.0);
   // tiles of the diagonal-block outputs that k_diag leaves alone (they are read as parts of full 128 x 128 operands)
-  hipLaunchKernelGGL(k_zero_diag_out<T>, dim3(m, q), dim3(NTHREADS), 0, st, Vd, strideV,
-                     with_inverse ? A + wcol0 : (T *)nullptr, lda, strideA, (int64_t)NB * lda + NB);
+  hipLaunchKernelGGL(k_zero_diag_out<T>, dim3(m > GMAX ? m : GMAX, q), dim3(NTHREADS), 0, st, Vd, strideV, m, Wg, (int64_t)LDG,
+                     strideV, (int64_t)NB * LDG + NB, GMAX);
   auto finish = [&]() {
     hipLaunchKernelGGL(k_logdet<T>, dim3(q), dim3(NTHREADS), 0, st, (const T *)A, n_pad, lda, strideA, logdet, info);
     return launch_status("potrf_impl");
   };
-  // Block rows are processed in GROUPS: within a group each diagonal block is factored/inverted, its row
-  // panel solved, and the next row of the group brought up to date (rank-(128 j) update with the rows of
-  // the group done so far); the rest of the matrix then gets ONE update of depth 128 * (group size).
-  // Deeper updates = less read-modify-write traffic on the trailing matrix, but the within-group work runs
-  // one block row at a time.  Measured on MI355X the schedule matters little (27.7 .. 28.3 ms for the sweep
-  // of the benchmark shape over a dozen schedules); large groups, smaller ones at the end, is the default.
+  // Group boundaries.  Large groups divide the read-modify-write traffic of the trailing matrix by G and put
+  // G (G + 1) / 2 tile products into every group-panel strip; the chain of a group costs ~3 G small launches.
   std::vector<int> gb;                                    // group boundaries: gb[i] .. gb[i+1]
   {
-    const char *genv = getenv("PLMC_GRP");                // dev knob: fixed group size
-    const int fixed = genv ? atoi(genv) : 0;
-    const int big = fixed > 0 ? fixed : ((q >= 8 && m >= 32) ? 8 : (q == 1 ? 3 : 4));   // measured per q on MI355X
-    int r = 0;
+    int big = knobs.grp > 0 ? knobs.grp : GMAX;
+    if (big > GMAX) big = GMAX;
     gb.push_back(0);
-    const char *senv = getenv("PLMC_GRP_SCHED");          // dev knob: explicit comma-separated group sizes
-    if (senv) {
-      const char *p = senv;
-      while (*p && r < m) {
-        int g = atoi(p);
-        if (g <= 0) break;
-        if (r + g > m) g = m - r;
-        r += g;
-        gb.push_back(r);
-        while (*p && *p != ',') ++p;
-        if (*p == ',') ++p;
-      }
-    }
-    while (r < m) {
+    for (int r = 0; r < m;) {
       int g = big;
-      if (fixed <= 0 && big > 4 && m - r <= 16) g = 4;    // ramp down: the chain is the bottleneck at the end
       if (r + g > m) g = m - r;
       r += g;
       gb.push_back(r);
     }
   }
   const int ng = (int)gb.size() - 1;
+  auto G0 = [&](int gi) { return gb[gi < ng ? gi : ng]; };   // first block row of group gi (m beyond the last group)
+
+  // ---- the pieces of one group gi (rows g0 .. g1-1; next group g1 .. g2-1; the one after g2 .. g3-1)
+  // chain: the group's diagonal triangle + its inverse triangle in Wg
   auto chain = [&](int gi, hipStream_t s) {
-    const int g0 = gb[gi], g1 = gb[gi + 1];
+    const int g0 = G0(gi), g1 = G0(gi + 1);
     for (int r = g0; r < g1; ++r) {
-      diag(r, s);
-      panel(r, s);
-      if (r + 1 < g1) update(r + 1, 1, g0, r, s, PK_TRAIL_ROW);
+      diag(r, g0, s);
+      panel(r, cm_tri(g0, r + 1, g1 - 1 - r, g0, r - g0), s);
+      if (r + 1 < g1) update(r + 1, 1, g0, r, cm_tri(g0, r + 1, g1 - r - 1, g0, r + 1 - g0), s, PK_TRAIL_ROW);
     }
   };
-  // The same chain with the inverse-factor columns taken off the critical path: the next diagonal block depends
-  // only on the U columns, so stream s carries diag / U panel / U row update and stream w follows one row behind
-  // with the W panel and W row update (their A operand is the U panel of the same rows: event e_row).
-  auto chain_split = [&](int gi, hipStream_t s, hipStream_t w, hipEvent_t e_row) {
-    const int g0 = gb[gi], g1 = gb[gi + 1];
-    for (int r = g0; r < g1; ++r) {
-      diag(r, s);
-      panel(r, s, 1);
-      (void)hipEventRecord(e_row, s);
-      (void)hipStreamWaitEvent(w, e_row, 0);
-      panel(r, w, 2);
-      if (r + 1 < g1) {
-        update(r + 1, 1, g0, r, s, PK_TRAIL_ROW, 1);
-        update(r + 1, 1, g0, r, w, PK_TRAIL_ROW, 2);
-      }
-    }
+  auto vtrans = [&](int gi, hipStream_t s) {
+    const int g0 = G0(gi), G = G0(gi + 1) - g0;
+    T *wo = WA ? WA + (int64_t)g0 * NB * lda + (int64_t)g0 * NB : (T *)nullptr;
+    hipLaunchKernelGGL(k_vtrans<T>, dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)Wg, strideV, Vg2[gi & 1], G, wo, lda,
+                       strideA);
   };
-  // Look-ahead on two streams.  C (helper, high priority) carries the latency-bound work: the chain of
-  // each group and the "head" update (the block rows the NEXT chain needs); T (the caller's stream) carries the
-  // "tail" update of all other rows.
-  //   head(g) needs chain(g) [same stream] and tail(g-1) [event, normally long complete];
-  //   tail(g) needs chain(g) [event] and tail(g-1) [same stream]; head(g) and tail(g) touch disjoint rows.
-  // C never waits on an event that is still pending when the chain is the bottleneck (few latents), and T
-  // runs its updates back to back when the updates are (many latents).  Falls back to one stream.
-  hipStream_t C = side_stream();
-  // dev knob PLMC_CUMASK=1: tail on a CU-masked stream (one CU per XCD kept free for the chain).  It paid when a
-  // diagonal-block workgroup needed 66 KB of LDS + 16 wave slots at once (2 % then); with the 19 KB / 8-wave
-  // kernel the tail is better off with all CUs (42.9 vs 43.5 ms/step), so the default is the caller's stream.
-  hipStream_t s2 = getenv("PLMC_CUMASK") ? tail_stream(8) : nullptr;
-  hipEvent_t e_chain = sync_event(0), e_tail = sync_event(1), e_entry = sync_event(2), e_done = sync_event(3);
-  const bool la = C && e_chain && e_tail && e_entry && e_done && ng > 2 && !getenv("PLMC_SERIAL");   // dev knob: one stream
+
+  hipStream_t C = serial ? nullptr : side_stream();
+  hipEvent_t e_entry = sync_event(0), e_v = sync_event(1), e_h = sync_event(2), e_tail = sync_event(3), e_done = sync_event(4);
+  const bool la = C && e_entry && e_v && e_h && e_tail && e_done && ng > 2;
   if (!la) {
-    chain(0, st);
-    for (int gi = 0; gi + 1 < ng; ++gi) {
-      update(gb[gi + 1], m - gb[gi + 1], gb[gi], gb[gi + 1] - 1, st, PK_TRAIL);
-      chain(gi + 1, st);
+    // one stream: chain -> transpose -> group panel over every column -> trailing update of every row below
+    for (int gi = 0; gi < ng; ++gi) {
+      const int g0 = G0(gi), g1 = G0(gi + 1);
+      chain(gi, st);
+      vtrans(gi, st);
+      gpanel(g0, g1 - g0, cm_buf(g1, m - g1, Taug, 0, g0), Vg2[gi & 1], st, 0);
+      update(g1, m - g1, g0, g1 - 1, cm_buf(g1, m - g1, Taug, 0, g1), st, PK_TRAIL);
     }
     return finish();
   }
-  // Three streams when the inverse factor is wanted and the launches are wide (dev knob PLMC_WSTREAM=0/1): the W
-  // columns of the chain and of the head rows run on a second helper stream Wc.
-  //   Wc: whead(g) [needs chain_U(g): e_chain, wchain(g): same stream, tail(g-1): e_tail] -> wchain(g+1)
-  //   T : tail(g)  [needs e_chain, e_wchain]
-  hipStream_t Wc = with_inverse ? side_stream(1) : nullptr;
-  hipEvent_t e_row = sync_event(4), e_wchain = sync_event(5), e_wdone = sync_event(6);
-  const char *wenv = getenv("PLMC_WSTREAM");
-  const bool wsplit = Wc && e_row && e_wchain && e_wdone && (wenv ? atoi(wenv) != 0 : q >= 4);
-  if (wsplit) {
-    (void)hipEventRecord(e_entry, st);
-    (void)hipStreamWaitEvent(C, e_entry, 0);
-    (void)hipStreamWaitEvent(Wc, e_entry, 0);
-    chain_split(0, C, Wc, e_row);
-    bool tail_pending = false;
-    for (int gi = 0; gi + 1 < ng; ++gi) {
-      const int g0 = gb[gi], g1 = gb[gi + 1], first = g1, nrest = m - first;
-      const int nhead = gb[gi + 2] - gb[gi + 1];
-      (void)hipEventRecord(e_chain, C);                     // U panels of group gi complete
-      (void)hipEventRecord(e_wchain, Wc);                   // W panels of group gi complete
-      if (tail_pending) {
-        (void)hipStreamWaitEvent(C, e_tail, 0);
-        (void)hipStreamWaitEvent(Wc, e_tail, 0);
-      }
-      update(first, nhead, g0, g1 - 1, C, PK_TRAIL_HEAD, 1);
-      (void)hipStreamWaitEvent(Wc, e_chain, 0);
-      update(first, nhead, g0, g1 - 1, Wc, PK_TRAIL_HEAD, 2);
-      tail_pending = nrest > nhead;
-      if (tail_pending) {
-        (void)hipStreamWaitEvent(st, e_chain, 0);
-        (void)hipStreamWaitEvent(st, e_wchain, 0);
-        update(first + nhead, nrest - nhead, g0, g1 - 1, st, PK_TRAIL);
-        (void)hipEventRecord(e_tail, st);
-      }
-      chain_split(gi + 1, C, Wc, e_row);
-    }
-    (void)hipEventRecord(e_done, C);
-    (void)hipEventRecord(e_wdone, Wc);
-    (void)hipStreamWaitEvent(st, e_done, 0);
-    (void)hipStreamWaitEvent(st, e_wdone, 0);
-    return finish();
-  }
-  hipStream_t Tq = s2 ? s2 : st;
+  // Look-ahead on two streams.  C (helper, high priority) carries the latency-bound work of group gi + 1 while T (the
+  // caller's stream) carries the bulk of group gi:
+  //   C: chain(gi) -> vtrans(gi) -> [e_v] -> (wait e_tail(gi - 1)) -> gpanel_head(gi): panel columns of the next
+  //      group -> U1(gi): update of the next group's triangle -> [e_h] -> chain(gi + 1) ...
+  //   T: (wait e_v) gpanel_rest(gi): every other column (U right of the next group, augmented, inverse-factor columns
+  //      left of the group) -> (wait e_h) tail(gi): every row below the group, all columns, minus the U1 tiles -> [e_tail].
+  // chain(gi + 1) needs U1(gi) only, so it runs beside tail(gi); gpanel_head(gi + 1) reads tiles tail(gi) wrote, hence
+  // the wait for e_tail before it.  vtrans(gi + 2) reuses the Vg copy gpanel_rest(gi) read: by then C has waited for
+  // e_tail(gi), recorded behind it.  U1 and tail touch disjoint tiles; every tile receives its updates in the same
+  // order as on one stream, so the result is bit-identical to the serial schedule (tests/test_gpu_edges.py).
   (void)hipEventRecord(e_entry, st);
   (void)hipStreamWaitEvent(C, e_entry, 0);
-  if (Tq != st) (void)hipStreamWaitEvent(Tq, e_entry, 0);
-  chain(0, C);
-  bool tail_pending = false, any_tail = false;
-  for (int gi = 0; gi + 1 < ng; ++gi) {
-    const int g0 = gb[gi], g1 = gb[gi + 1], first = g1, nrest = m - first;
-    const int nhead = gb[gi + 2] - gb[gi + 1];              // rows of the next group
-    (void)hipEventRecord(e_chain, C);                       // panels of group gi complete
-    if (tail_pending) (void)hipStreamWaitEvent(C, e_tail, 0);
-    update(first, nhead, g0, g1 - 1, C, PK_TRAIL_HEAD);
-    tail_pending = nrest > nhead;
-    if (tail_pending) {
-      (void)hipStreamWaitEvent(Tq, e_chain, 0);
-      update(first + nhead, nrest - nhead, g0, g1 - 1, Tq, PK_TRAIL);
-      (void)hipEventRecord(e_tail, Tq);
-      any_tail = true;
-    }
-    chain(gi + 1, C);
+  for (int gi = 0; gi < ng; ++gi) {
+    const int g0 = G0(gi), g1 = G0(gi + 1), g2 = G0(gi + 2), G = g1 - g0;
+    const T *Vg = Vg2[gi & 1];
+    chain(gi, C);
+    vtrans(gi, C);
+    (void)hipEventRecord(e_v, C);
+    if (gi > 0) (void)hipStreamWaitEvent(C, e_tail, 0);                       // tail(gi - 1): rows of this group final
+    gpanel(g0, G, cm_buf(g1, g2 - g1, 0, 0, 0), Vg, C, 1);                      // head: columns of the next group
+    update(g1, g2 - g1, g0, g1 - 1, cm_buf(g1, g2 - g1, 0, 0, 0), C, PK_TRAIL_HEAD);   // U1: next triangle
+    (void)hipEventRecord(e_h, C);
+    (void)hipStreamWaitEvent(st, e_v, 0);
+    gpanel(g0, G, cm_buf(g2, m - g2, Taug, 0, g0), Vg, st, 0);                  // rest
+    (void)hipStreamWaitEvent(st, e_h, 0);
+    update(g1, m - g1, g0, g1 - 1, cm_buf(g1, m - g1, Taug, 0, g1), st, PK_TRAIL, g2, g2);   // tail (skips the U1 tiles)
+    (void)hipEventRecord(e_tail, st);
   }
   (void)hipEventRecord(e_done, C);
   (void)hipStreamWaitEvent(st, e_done, 0);
-  if (any_tail && Tq != st) (void)hipStreamWaitEvent(st, e_tail, 0);
   return finish();
 }
 
@@ -433,6 +485,7 @@ int wt_matvec_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, cons
 }  // namespace plmc
 
 extern "C" {
+int64_t plmc_vd_blocks(int64_t n_pad) { return n_pad / plmc::NB + plmc::VD_EXTRA_BLOCKS; }
 int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet,
                    int *info, int with_inverse, int q, void *stream) {
   return plmc::potrf_impl<float>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, stream);

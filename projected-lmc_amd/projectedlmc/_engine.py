@@ -36,7 +36,7 @@ class Workspace:
         self.strideA = self.n_pad * self.lda
         self.m = self.n_pad // self.NB
         self.A = torch.empty(q, self.n_pad, self.lda, dtype=dtype, device=device)
-        self.Vd = torch.empty(q, self.m, self.NB, self.NB, dtype=dtype, device=device)
+        self.Vd = torch.empty(q, int(L.cdll.plmc_vd_blocks(self.n_pad)), self.NB, self.NB, dtype=dtype, device=device)
         self.logdet = torch.empty(q, dtype=torch.float64, device=device)
         self.quad = torch.empty(q, dtype=torch.float64, device=device)
         self.info = torch.empty(q, dtype=torch.int32, device=device)
