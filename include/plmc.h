@@ -24,9 +24,9 @@
  *                                           sweep (explicit zeros above the diagonal inside diagonal
  *                                           blocks; blocks strictly above the diagonal are never touched).
  *     The strictly lower triangle of the square part is never read.
- *   - Vd: per latent plmc_vd_blocks(n_pad) blocks of NB x NB: the first n_pad/NB are the inverses of the diagonal
+ *   - Vd: per latent plmc_vd_blocks(n_pad, lda) blocks of NB x NB: the first n_pad/NB are the inverses of the diagonal
  *     blocks of U (upper), the rest is workspace of the sweep (the inverse triangle of the current group of block
- *     rows and its transposed copies).
+ *     rows, its transposed copies and the panel buffers of the group's block rows).
  *   - "W, ldw, strideW" arguments below: pointer to the first W column of latent 0 inside the factor
  *     buffer (A + n_pad + naug_pad), ldw = lda, strideW = strideA -- or any buffer of that layout.
  *   - kernel kinds: PLMC_RBF, PLMC_MATERN12, PLMC_MATERN32, PLMC_MATERN52.
@@ -49,7 +49,7 @@ int         plmc_block(void);                 /* NB (128) */
 int64_t     plmc_pad(int64_t n);              /* n rounded up to a multiple of NB */
 int         plmc_max_dim(void);               /* largest input dimension d accepted by the fused kernels */
 const char *plmc_last_error(void);            /* text of the last error on the calling thread */
-int64_t     plmc_vd_blocks(int64_t n_pad);    /* NB x NB blocks per latent the `Vd` argument of plmc_potrf_* must hold */
+int64_t     plmc_vd_blocks(int64_t n_pad, int64_t lda);   /* NB x NB blocks per latent the `Vd` argument of plmc_potrf_* must hold */
 /* Bytes of the `partials` scratch plmc_kinv_grad_* needs for (n_pad, q). */
 int64_t     plmc_grad_scratch_bytes(int64_t n_pad, int q);
 

@@ -1,4 +1,5 @@
 // api.hip -- library identification, error text, and the optional per-kernel HIP-event profiler.
+#include <stdlib.h>
 #include <vector>
 
 #include "api_common.hpp"
@@ -52,24 +53,6 @@ hipStream_t side_stream(int which) {
     if (hipStreamCreateWithPriority(&g_side[dev], hipStreamNonBlocking, hi) != hipSuccess) g_side[dev] = nullptr;
   }
   return g_side[dev];
-}
-// Stream for the big trailing updates with a few CUs masked out: those CUs stay free for the
-// latency-bound chain kernels (a diagonal-block workgroup needs 66 KB of LDS and 16 wave slots, which a CU
-// busy with update tiles never has free at once).  Speed only; nullptr -> caller falls back.
-static hipStream_t g_tail[64] = {nullptr};
-hipStream_t tail_stream(int reserve_cus) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (!g_tail[dev]) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
-    const int ncu = prop.multiProcessorCount, nw = (ncu + 31) / 32;
-    if (ncu <= 2 * reserve_cus) return nullptr;
-    std::vector<uint32_t> mask(nw, 0xffffffffu);
-    for (int c = 0; c < reserve_cus; ++c) mask[c / 32] &= ~(1u << (c % 32));
-    if (hipExtStreamCreateWithCUMask(&g_tail[dev], (uint32_t)nw, mask.data()) != hipSuccess) g_tail[dev] = nullptr;
-  }
-  return g_tail[dev];
 }
 hipEvent_t sync_event(int idx) {
   int dev = 0;

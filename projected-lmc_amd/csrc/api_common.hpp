@@ -44,7 +44,6 @@ struct ProfScope {
 };
 
 hipStream_t side_stream(int which = 0);   // per-device helper streams (api.hip), which in {0, 1}; nullptr on failure
-hipStream_t tail_stream(int reserve_cus);   // per-device stream with the first CUs masked out, or nullptr
 hipEvent_t sync_event(int idx);     // per-device ordering events, idx in [0,8)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

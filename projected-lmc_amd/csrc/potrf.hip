@@ -30,9 +30,11 @@
 namespace plmc {
 
 constexpr int GMAX = 8;                       // largest group (block rows)
-constexpr int LDG = GMAX * NB;                // leading dimension of the group scratch matrices (Wg, Vg)
+constexpr int LDG = (GMAX + 1) * NB;          // leading dimension of the group scratch matrices (Wg, Vg, Ph): an odd number of
+                                              // 128-blocks, like lda -- a power-of-two row stride camps on a few L2 channels
 // per-latent scratch behind the m inverse diagonal blocks of Vd: Wg + two Vg (ping-pong), GMAX^2 blocks each
-constexpr int VD_EXTRA_BLOCKS = 3 * GMAX * GMAX;
+// + the head panel buffer (GMAX^2 blocks) + the bulk panel buffer (GMAX block rows of lda / NB blocks)
+constexpr int VD_FIXED_BLOCKS = 4 * GMAX * (GMAX + 1);
 
 // Column-tile decoding shared by k_panel / k_update / k_gpanel.  Tiles along grid.x are laid out as
 //   [ U block columns u0 .. u0+nU-1 | aug tiles (Taug) | W block columns w0 .. w0+nW-1 ].
@@ -125,18 +127,21 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
   else tile_writeback<T, WB_SUB, MT>(acc, C, ldc, smem);               // C -= P^T P
 }
 
-// Group panel: for one 128-column strip (grid.x, decoded by ColMap) of the group's block rows g0 .. g0+G-1,
-//     P[i] = sum_{k <= i} Vgg[k][i]^T A[k]      (i = G-1 ... 0, in place)
-// with Vgg = Ugg^-1 (upper, K-major, leading dimension ldv) -- U^-T applied to the whole block row as G products of
-// depth 128 (i + 1).  Going DOWN in i makes the in-place update safe inside the workgroup that owns the strip: row i
-// is only read by the products of rows >= i, which are done when it is overwritten.  grid (tiles, q, 4 / NT).
-template <typename T, int NT>
-__global__ __launch_bounds__(NTHREADS, (sizeof(T) == 8 ? 2 : 4)) void k_gpanel(T *A, int64_t lda, int64_t strideA, int g0, int G, ColMap<T> cm,
-                                                      const T *__restrict__ Vg, int64_t ldv, int64_t strideVg, int prio) {
-  if (prio) __builtin_amdgcn_s_setprio(2);
+// Group panel: U^-T applied to the whole block row of the group as products with Vgg = Ugg^-1 (upper, K-major, leading
+// dimension ldv).  One workgroup per (128-column strip t of the column map, block row i of the group):
+//     Pb[i][t] = sum_{k <= i} Vgg[k][i]^T A[k][strip t]         (depth 128 (i + 1))
+// written OUT OF PLACE into the panel buffer Pb (G x tiles tiles, leading dimension ldp) -- in place, the workgroup
+// of row i would overwrite what the workgroups of rows > i still read -- and copied back by k_gpanel_copy.  (A strip
+// form, one workgroup walking i = G-1 .. 0 in place, needs no buffer but has G times fewer workgroups: 61 TF at q = 8,
+// 15 TF at q = 1 on the benchmark shape.)  Heavy rows first.  grid (tiles, G, q).
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, (sizeof(T) == 8 ? 2 : 4)) void k_gpanel_rows(const T *A, int64_t lda, int64_t strideA, int g0, int G,
+                                                           ColMap<T> cm, const T *__restrict__ Vg, int64_t ldv, int64_t strideVg,
+                                                           T *__restrict__ Pb, int64_t ldp, int64_t strideP, int head) {
+  if (head) __builtin_amdgcn_s_setprio(2);
   __shared__ __align__(16) T smem[tile_smem_elems<T>()];
-  const int lat = blockIdx.y, t = blockIdx.x;
-  T *S;
+  const int lat = blockIdx.z, t = blockIdx.x;
+  const T *S;
   int64_t lds = lda;
   if (t < cm.nU) S = A + (int64_t)lat * strideA + (int64_t)g0 * NB * lda + (int64_t)(cm.u0 + t) * NB;
   else if (t < cm.nU + cm.Taug) S = A + (int64_t)lat * strideA + (int64_t)g0 * NB * lda + cm.n_pad + (int64_t)(t - cm.nU) * NB;
@@ -144,19 +149,42 @@ __global__ __launch_bounds__(NTHREADS, (sizeof(T) == 8 ? 2 : 4)) void k_gpanel(T
     lds = cm.ldw;
     S = cm.W + (int64_t)lat * cm.strideW + (int64_t)g0 * NB * lds + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
   }
-  S += (int)blockIdx.z * (32 * NT);
-  const T *V = Vg + (int64_t)lat * strideVg;
+  // head launch (latency-critical, few strips): one block row per workgroup, heavy rows first.  Bulk launch: rows
+  // y and G-1-y share a workgroup -- every workgroup then carries depth 128 (G + 1) instead of 128 .. 128 G, and the
+  // short products no longer dominate the launch (77 -> ~100 TF at q = 8)
+  const int y = blockIdx.y;
+  const int i0 = head ? G - 1 - y : G - 1 - y, i1 = head ? -1 : (y < G - 1 - y ? y : -1);
 #pragma unroll 1
-  for (int i = G - 1; i >= 0; --i) {
-    Acc<T, 4, NT> acc;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int i = pass == 0 ? i0 : i1;
+    if (i < 0) break;
+    Acc<T> acc;
     acc.zero();
-    tile_mainloop<T, false, false, 4, NT>(acc, V + (int64_t)i * NB, ldv, S, lds, (i + 1) * NB, smem);
-    if constexpr (NT == 4) {
-      tile_writeback<T, WB_STORE, 4>(acc, S + (int64_t)i * NB * lds, lds, smem);
-      __syncthreads();                 // staging buffer free before the next product refills it
-    } else {
-      tile_store<T, 4, NT>(acc, S + (int64_t)i * NB * lds, lds);
-    }
+    tile_mainloop<T, false, false>(acc, Vg + (int64_t)lat * strideVg + (int64_t)i * NB, ldv, S, lds, (i + 1) * NB, smem);
+    tile_writeback<T, WB_STORE>(acc, Pb + (int64_t)lat * strideP + (int64_t)i * NB * ldp + (int64_t)t * NB, ldp, smem);
+    __syncthreads();                   // staging buffer free before the second product refills it
+  }
+}
+
+// Panel buffer -> factor buffer (block row g0 + i, column strip t of the column map).  grid (tiles, G, q); HBM-bound.
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_gpanel_copy(T *A, int64_t lda, int64_t strideA, int g0, ColMap<T> cm, const T *__restrict__ Pb,
+                                                          int64_t ldp, int64_t strideP) {
+  using vec_t = typename Traits<T>::vec_t;
+  constexpr int EPV = Traits<T>::EPV, CPR = NB / EPV;
+  const int lat = blockIdx.z, t = blockIdx.x, i = blockIdx.y;
+  T *D;
+  int64_t ldd = lda;
+  if (t < cm.nU) D = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + (int64_t)(cm.u0 + t) * NB;
+  else if (t < cm.nU + cm.Taug) D = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + cm.n_pad + (int64_t)(t - cm.nU) * NB;
+  else {
+    ldd = cm.ldw;
+    D = cm.W + (int64_t)lat * cm.strideW + (int64_t)(g0 + i) * NB * ldd + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
+  }
+  const T *S = Pb + (int64_t)lat * strideP + (int64_t)i * NB * ldp + (int64_t)t * NB;
+  for (int c = threadIdx.x; c < NB * CPR; c += NTHREADS) {
+    const int r = c / CPR, col = (c % CPR) * EPV;
+    *reinterpret_cast<vec_t *>(D + (int64_t)r * ldd + col) = *reinterpret_cast<const vec_t *>(S + (int64_t)r * ldp + col);
   }
 }
 
@@ -275,13 +303,15 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const hipStream_t st = (hipStream_t)stream;
   const int m = (int)(n_pad / NB);
   const int Taug = (int)(naug_pad / NB);
-  const int64_t strideV = plmc_vd_blocks(n_pad) * (int64_t)NB * NB;      // per latent: m diagonal inverses + group scratch
+  const int64_t strideV = plmc_vd_blocks(n_pad, lda) * (int64_t)NB * NB; // per latent: m diagonal inverses + group scratch
   const int64_t wcol0 = n_pad + naug_pad;
   const double nb = (double)NB, nb3 = nb * nb * nb, esz = sizeof(T);
   // group scratch of latent 0 (batch stride strideV): the inverse triangle Wg and two transposed copies (ping-pong:
   // the group panel of one group may still read its copy while the chain of the next group writes the other)
   T *const Wg = Vd + (int64_t)m * NB * NB;
   T *const Vg2[2] = {Wg + (int64_t)GMAX * NB * LDG, Wg + 2 * (int64_t)GMAX * NB * LDG};
+  T *const Ph = Wg + 3 * (int64_t)GMAX * NB * LDG;                      // panel buffer of the head columns (ld LDG)
+  T *const Pbulk = Ph + (int64_t)GMAX * NB * LDG;                       // panel buffer of the other columns (ld lda)
   T *const WA = with_inverse ? A + wcol0 : (T *)nullptr;                // inverse-factor columns of the factor buffer
 
   // env knobs are dev aids; read once per process (getenv is not free and the values never change under a run)
@@ -357,15 +387,19 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     else PLMC_UPD(0, 4);
 #undef PLMC_UPD
   };
-  auto gpanel = [&](int g0, int G, const ColMap<T> &cm, const T *Vg, hipStream_t s, int prio) {
+  // head != 0: the few columns of the next group (panel buffer Ph), on the chain stream
+  auto gpanel = [&](int g0, int G, const ColMap<T> &cm, const T *Vg, hipStream_t s, int head) {
     const int nt = cm.nU + cm.Taug + cm.nW;
     if (nt == 0) return;
     const double prods = G * (G + 1) / 2.0;               // 128-deep tile products per column strip
-    ProfScope ps(PK_GPANEL, s, q * (double)nt * prods * 2.0 * nb3, q * (double)nt * (prods + G) * nb * nb * esz);
-    if ((double)nt * q <= hthr)
-      hipLaunchKernelGGL((k_gpanel<T, 2>), dim3(nt, q, 2), dim3(NTHREADS), 0, s, A, lda, strideA, g0, G, cm, Vg, (int64_t)LDG, strideV, prio);
-    else
-      hipLaunchKernelGGL((k_gpanel<T, 4>), dim3(nt, q, 1), dim3(NTHREADS), 0, s, A, lda, strideA, g0, G, cm, Vg, (int64_t)LDG, strideV, prio);
+    T *Pb = head ? Ph : Pbulk;
+    const int64_t ldp = head ? (int64_t)LDG : lda;
+    {
+      ProfScope ps(PK_GPANEL, s, q * (double)nt * prods * 2.0 * nb3, q * (double)nt * (prods + G) * nb * nb * esz);
+      hipLaunchKernelGGL((k_gpanel_rows<T>), dim3(nt, head ? G : (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)A, lda, strideA, g0, G, cm,
+                         Vg, (int64_t)LDG, strideV, Pb, ldp, strideV, head);
+    }
+    hipLaunchKernelGGL((k_gpanel_copy<T>), dim3(nt, G, q), dim3(NTHREADS), 0, s, A, lda, strideA, g0, cm, (const T *)Pb, ldp, strideV);
   };
 
   // whole-sweep bracket on the caller's stream (the per-kernel records of overlapped kernels add up to
@@ -403,7 +437,10 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     for (int r = g0; r < g1; ++r) {
       diag(r, g0, s);
       panel(r, cm_tri(g0, r + 1, g1 - 1 - r, g0, r - g0), s);
-      if (r + 1 < g1) update(r + 1, 1, g0, r, cm_tri(g0, r + 1, g1 - r - 1, g0, r + 1 - g0), s, PK_TRAIL_ROW);
+      // right-looking inside the triangle: every remaining row of the group gets the rank-128 update of row r at once
+      // (depth 128 per launch; a left-looking row update grows to depth 128 (G - 1) on ONE workgroup's critical path:
+      // 10 -> 43 us per launch at G = 8).  W columns g0 .. r: column r is touched for the first time (plain store).
+      if (r + 1 < g1) update(r + 1, g1 - r - 1, r, r, cm_tri(g0, r + 1, g1 - r - 1, g0, r + 1 - g0), s, PK_TRAIL_ROW);
     }
   };
   auto vtrans = [&](int gi, hipStream_t s) {
@@ -413,9 +450,10 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
                        strideA);
   };
 
-  hipStream_t C = serial ? nullptr : side_stream();
-  hipEvent_t e_entry = sync_event(0), e_v = sync_event(1), e_h = sync_event(2), e_tail = sync_event(3), e_done = sync_event(4);
-  const bool la = C && e_entry && e_v && e_h && e_tail && e_done && ng > 2;
+  hipStream_t C = serial ? nullptr : side_stream(), H = serial ? nullptr : side_stream(1);
+  hipEvent_t e_entry = sync_event(0), e_v = sync_event(1), e_gh = sync_event(2), e_p = sync_event(3), e_hd = sync_event(4),
+             e_tail = sync_event(5), e_doneC = sync_event(6), e_doneH = sync_event(7);
+  const bool la = C && H && e_entry && e_v && e_gh && e_p && e_hd && e_tail && e_doneC && e_doneH && ng > 2;
   if (!la) {
     // one stream: chain -> transpose -> group panel over every column -> trailing update of every row below
     for (int gi = 0; gi < ng; ++gi) {
@@ -427,36 +465,50 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     }
     return finish();
   }
-  // Look-ahead on two streams.  C (helper, high priority) carries the latency-bound work of group gi + 1 while T (the
-  // caller's stream) carries the bulk of group gi:
-  //   C: chain(gi) -> vtrans(gi) -> [e_v] -> (wait e_tail(gi - 1)) -> gpanel_head(gi): panel columns of the next
-  //      group -> U1(gi): update of the next group's triangle -> [e_h] -> chain(gi + 1) ...
-  //   T: (wait e_v) gpanel_rest(gi): every other column (U right of the next group, augmented, inverse-factor columns
-  //      left of the group) -> (wait e_h) tail(gi): every row below the group, all columns, minus the U1 tiles -> [e_tail].
-  // chain(gi + 1) needs U1(gi) only, so it runs beside tail(gi); gpanel_head(gi + 1) reads tiles tail(gi) wrote, hence
-  // the wait for e_tail before it.  vtrans(gi + 2) reuses the Vg copy gpanel_rest(gi) read: by then C has waited for
-  // e_tail(gi), recorded behind it.  U1 and tail touch disjoint tiles; every tile receives its updates in the same
-  // order as on one stream, so the result is bit-identical to the serial schedule (tests/test_gpu_edges.py).
+  // Look-ahead on three streams.  With R0 = the rows of group gi, R1 = the next group, R2 = the one after:
+  //   C (helper, high priority; latency-bound): chain(gi) -> vtrans(gi) -> [e_v] -> (wait e_hd(gi-1)) gpanel_head(gi):
+  //       panel columns R1 -> [e_gh] -> (wait e_tail(gi-1)) U1(gi): update of the next triangle R1 x R1 -> chain(gi+1) ...
+  //   H (helper): (wait e_v) gpanel_rest(gi): every other panel column (U right of R1, augmented, inverse-factor columns
+  //       left of the group) -> [e_p] -> (wait e_gh, e_tail(gi-1)) head(gi): rows R1, every column but R1 -> [e_hd]
+  //   T (the caller's stream; bulk): (wait e_p, e_gh) tail(gi): rows below R1, every column -> [e_tail]
+  // chain(gi+1) needs U1(gi) only and runs beside tail(gi); gpanel_rest(gi+1) needs head(gi) (same stream) and runs
+  // beside tail(gi) as well, so the bulk stream never waits for a panel.  gpanel_head(gi+1) reads tiles head(gi) wrote
+  // (e_hd); U1(gi+1) and head(gi+1) rewrite rows tail(gi) wrote (e_tail).  vtrans(gi+2) reuses the Vg copy
+  // gpanel_rest(gi) read: by then C has waited for e_hd(gi), recorded behind it.  U1 / head / tail touch disjoint
+  // tiles; every tile receives its updates in the same order as on one stream, so the result is bit-identical to the
+  // serial schedule (tests/test_gpu_edges.py).
   (void)hipEventRecord(e_entry, st);
   (void)hipStreamWaitEvent(C, e_entry, 0);
+  (void)hipStreamWaitEvent(H, e_entry, 0);
   for (int gi = 0; gi < ng; ++gi) {
     const int g0 = G0(gi), g1 = G0(gi + 1), g2 = G0(gi + 2), G = g1 - g0;
     const T *Vg = Vg2[gi & 1];
     chain(gi, C);
     vtrans(gi, C);
     (void)hipEventRecord(e_v, C);
-    if (gi > 0) (void)hipStreamWaitEvent(C, e_tail, 0);                       // tail(gi - 1): rows of this group final
-    gpanel(g0, G, cm_buf(g1, g2 - g1, 0, 0, 0), Vg, C, 1);                      // head: columns of the next group
+    if (gi > 0) (void)hipStreamWaitEvent(C, e_hd, 0);                          // head(gi - 1): rows R0 final
+    gpanel(g0, G, cm_buf(g1, g2 - g1, 0, 0, 0), Vg, C, 1);                      // head columns R1
+    (void)hipEventRecord(e_gh, C);
+    if (gi > 0) (void)hipStreamWaitEvent(C, e_tail, 0);                        // tail(gi - 1): rows R1 up to date
     update(g1, g2 - g1, g0, g1 - 1, cm_buf(g1, g2 - g1, 0, 0, 0), C, PK_TRAIL_HEAD);   // U1: next triangle
-    (void)hipEventRecord(e_h, C);
-    (void)hipStreamWaitEvent(st, e_v, 0);
-    gpanel(g0, G, cm_buf(g2, m - g2, Taug, 0, g0), Vg, st, 0);                  // rest
-    (void)hipStreamWaitEvent(st, e_h, 0);
-    update(g1, m - g1, g0, g1 - 1, cm_buf(g1, m - g1, Taug, 0, g1), st, PK_TRAIL, g2, g2);   // tail (skips the U1 tiles)
+
+    (void)hipStreamWaitEvent(H, e_v, 0);
+    gpanel(g0, G, cm_buf(g2, m - g2, Taug, 0, g0), Vg, H, 0);                   // rest of the panel columns
+    (void)hipEventRecord(e_p, H);
+    (void)hipStreamWaitEvent(H, e_gh, 0);
+    if (gi > 0) (void)hipStreamWaitEvent(H, e_tail, 0);
+    update(g1, g2 - g1, g0, g1 - 1, cm_buf(g2, m - g2, Taug, 0, g1), H, PK_TRAIL_HEAD);   // head: rows R1, columns right of R1
+    (void)hipEventRecord(e_hd, H);
+
+    (void)hipStreamWaitEvent(st, e_p, 0);
+    (void)hipStreamWaitEvent(st, e_gh, 0);
+    update(g2, m - g2, g0, g1 - 1, cm_buf(g2, m - g2, Taug, 0, g1), st, PK_TRAIL);         // tail: rows below R1
     (void)hipEventRecord(e_tail, st);
   }
-  (void)hipEventRecord(e_done, C);
-  (void)hipStreamWaitEvent(st, e_done, 0);
+  (void)hipEventRecord(e_doneC, C);
+  (void)hipEventRecord(e_doneH, H);
+  (void)hipStreamWaitEvent(st, e_doneC, 0);
+  (void)hipStreamWaitEvent(st, e_doneH, 0);
   return finish();
 }
 
@@ -485,7 +537,9 @@ int wt_matvec_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, cons
 }  // namespace plmc
 
 extern "C" {
-int64_t plmc_vd_blocks(int64_t n_pad) { return n_pad / plmc::NB + plmc::VD_EXTRA_BLOCKS; }
+int64_t plmc_vd_blocks(int64_t n_pad, int64_t lda) {
+  return n_pad / plmc::NB + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ((lda + plmc::NB - 1) / plmc::NB);
+}
 int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet,
                    int *info, int with_inverse, int q, void *stream) {
   return plmc::potrf_impl<float>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, stream);

@@ -34,9 +34,10 @@ class Workspace:
         if (self.lda // self.NB) % 2 == 0:
             self.lda += self.NB          # odd number of blocks per row: keeps the row stride off a power of two
         self.strideA = self.n_pad * self.lda
+        self.Vd = torch.empty(q, int(L.cdll.plmc_vd_blocks(self.n_pad, self.lda)), self.NB, self.NB, dtype=dtype, device=device)
         self.m = self.n_pad // self.NB
         self.A = torch.empty(q, self.n_pad, self.lda, dtype=dtype, device=device)
-        self.Vd = torch.empty(q, int(L.cdll.plmc_vd_blocks(self.n_pad)), self.NB, self.NB, dtype=dtype, device=device)
+        
         self.logdet = torch.empty(q, dtype=torch.float64, device=device)
         self.quad = torch.empty(q, dtype=torch.float64, device=device)
         self.info = torch.empty(q, dtype=torch.int32, device=device)

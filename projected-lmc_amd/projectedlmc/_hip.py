@@ -39,7 +39,7 @@ _PLAIN = {
     "plmc_version": ([], _I),
     "plmc_block": ([], _I),
     "plmc_pad": ([_L], _L),
-    "plmc_vd_blocks": ([_L], _L),
+    "plmc_vd_blocks": ([_L, _L], _L),
     "plmc_max_dim": ([], _I),
     "plmc_qr_max": ([], _I),
     "plmc_last_error": ([], _c.c_char_p),
