@@ -55,12 +55,27 @@ class Workspace:
 _ws_cache = {}
 
 
+def _release(ws):
+    """Before a workspace's memory goes back to the caching allocator: the gradient kernel of its last evaluation may
+    still read W / alpha and write the partials on the gradient stream -- make the allocating (current) stream wait."""
+    pending = getattr(ws, "pending", None)
+    if pending is not None:
+        torch.cuda.current_stream(ws.device).wait_event(pending)
+        ws.pending = None
+
+
+def _drop_all():
+    for ws in _ws_cache.values():
+        _release(ws)
+    _ws_cache.clear()
+
+
 def get_workspace(n, q, naug, dtype, device, need_grad):
     key = (n, q, naug, dtype, device.index, bool(need_grad))
     ws = _ws_cache.get(key)
     if ws is None:
         if len(_ws_cache) > 3:
-            _ws_cache.clear()
+            _drop_all()
         ws = Workspace(n, q, naug, dtype, device, need_grad)
         _ws_cache[key] = ws
     # a gradient kernel of the previous evaluation may still be reading this workspace on the gradient stream
@@ -88,7 +103,7 @@ def grad_stream(device):
 
 
 def free_workspaces():
-    _ws_cache.clear()
+    _drop_all()
 
 
 def _contig(t, dtype=None):
@@ -231,7 +246,7 @@ class ExactLatentLogProb(torch.autograd.Function):
                 gst = st
                 if gs is not None:
                     gs.wait_stream(torch.cuda.current_stream(dev))
-                    gst = _hip._c.c_void_p(gs.cuda_stream)
+                    gst = _hip.stream_handle(gs, dev)
                     for t in (grad, Xc, ellc, osc):
                         if t is not None:
                             t.record_stream(gs)

@@ -100,8 +100,18 @@ class _Lib:
                 fn.argtypes, fn.restype = args, _I
 
     def call(self, base, dtype, *args):
+        """Typed entry point.  The library picks its helper streams / ordering events by the CURRENT HIP device, so the
+        call runs with the device of its stream argument current (stream_ptr / stream_handle record it; a model moved
+        with .to('cuda:1') while cuda:0 is current would otherwise queue device-0 helper streams against device-1
+        memory)."""
         suf = "_f32" if dtype == torch.float32 else "_f64"
-        rc = getattr(self.cdll, base + suf)(*args)
+        fn = getattr(self.cdll, base + suf)
+        device = next((a.device for a in reversed(args) if isinstance(a, StreamHandle)), None)
+        if device is not None and device.index is not None and device.index != torch.cuda.current_device():
+            with torch.cuda.device(device):
+                rc = fn(*args)
+        else:
+            rc = fn(*args)
         if rc != 0:
             raise RuntimeError("%s%s failed (%d): %s" % (base, suf, rc, self.cdll.plmc_last_error().decode()))
 
@@ -120,8 +130,21 @@ def ptr(t):
     return None if t is None else _c.c_void_p(t.data_ptr())
 
 
+class StreamHandle(_c.c_void_p):
+    """hipStream_t for the C ABI that remembers its device (see _Lib.call)."""
+    device = None
+
+
+def stream_handle(stream, device):
+    h = StreamHandle(stream.cuda_stream)
+    h.device = torch.device(device) if not isinstance(device, torch.device) else device
+    if h.device.index is None:
+        h.device = torch.device("cuda", torch.cuda.current_device())
+    return h
+
+
 def stream_ptr(device):
-    return _c.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return stream_handle(torch.cuda.current_stream(device), device)
 
 
 def require_device(*tensors):

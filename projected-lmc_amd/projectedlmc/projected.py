@@ -27,6 +27,24 @@ from .models import (ExactGP, ExactGPModel, init_lmc_coefficients, ScalarParam, 
                      UpperTriangularParam, LowerTriangularParam)
 
 
+import weakref
+
+# Step-local caches (QR of the mixing matrix, Q^T Y^T) live OUTSIDE the modules: they hold non-leaf tensors, and a
+# parametrized module is deep-copied through its __dict__ (torch.nn.utils.parametrize), __getstate__ or not.
+_STEP_CACHE = weakref.WeakKeyDictionary()
+
+
+def _cache_get(mod, name):
+    return _STEP_CACHE.get(mod, {}).get(name)
+
+
+def _cache_set(mod, name, value):
+    if value is None:
+        _STEP_CACHE.get(mod, {}).pop(name, None)
+    else:
+        _STEP_CACHE.setdefault(mod, {})[name] = value
+
+
 class LMCMixingMatrix(torch.nn.Module):
     """Mixing matrix H = Q R (p x q), stored either in bulk (free matrix `H`, re-factored by QR at
     every call) or as separately parametrised `Q_plus`, `R` (projected_lmc.py:819-890)."""
@@ -61,27 +79,31 @@ class LMCMixingMatrix(torch.nn.Module):
     def Q_orth(self):
         return self.Q_plus[:, self.n_latents:]
 
-    def QR(self):
-        """(Q, R, Q_orth).  Bulk mode re-factors H at every call in the reference (:864-875), and a training step
-        calls it twice on the same H (projection :1015, MLL terms :1208); the factorisation is ~60 tiny
-        device kernels plus their backward, so the result is reused while H is unchanged (same tensor
-        version, same grad mode) -- identical values, one autograd node feeding both uses."""
+    def QR(self, store=False, reuse=False):
+        """(Q, R, Q_orth).  Bulk mode re-factors H at every call in the reference (:864-875), and a training step calls
+        it twice on the same H (projection :1015, MLL terms :1208); the factorisation is one device launch plus its
+        backward, so ONE result is shared inside a training step and nowhere else: `project_data` stores it
+        (store=True, only while training with grad enabled), `ProjectedLMCmll.forward` picks it up (reuse=True) and
+        drops it.  Every other caller (eval-mode posterior, full_likelihood, projection_matrix) factors afresh, as the
+        reference does -- a cache there would survive in-place edits through H.data (no version bump), hold non-leaf
+        tensors in the module (deepcopy fails) and hand an already back-propagated graph to the next step."""
         q = self.n_latents
         if self.bulk:
-            key = (self.H._version, self.H.data_ptr(), torch.is_grad_enabled(), self.H.dtype, self.H.device)
-            cached = getattr(self, "_qr_cache", None)
-            if cached is None or cached[0] != key:
+            key = (self.H._version, self.H.data_ptr(), self.H.dtype, self.H.device)
+            cached = _cache_get(self, "qr") if reuse else None
+            if cached is not None and cached[0] == key:
+                _, Qf, Rf = cached
+            else:
                 Qf, Rf = _qr.qr(self.H)
-                cached = (key, Qf, Rf)
-                object.__setattr__(self, "_qr_cache", cached)
-            _, Qf, Rf = cached
+                if store and self.training and torch.is_grad_enabled():
+                    _cache_set(self, "qr", (key, Qf, Rf))
             if self.mode == 'Q_plus':
                 return Qf[:, :q], Rf[:q, :q], Qf[:, q:]
             return Qf, Rf, None
         return self.Q(), self.R, self.Q_orth()
 
     def drop_qr_cache(self):
-        object.__setattr__(self, "_qr_cache", None)
+        _cache_set(self, "qr", None)
 
     def forward(self):
         if self.bulk:
@@ -164,6 +186,12 @@ class ProjectedGPModel(ExactGPModel):
             self.latent_ids = None
         else:
             rank, world = shard
+            if not (0 <= rank < world):
+                raise ValueError("latent_shard = (rank, world) needs 0 <= rank < world, got %r" % (shard,))
+            if world > self.n_latents:
+                raise ValueError("latent_shard: %d ranks for %d latent processes -- ranks beyond the number of latents "
+                                 "would own nothing and block the all-reduce; shard over at most n_latents ranks"
+                                 % (world, self.n_latents))
             self.latent_ids = list(range(rank, self.n_latents, world))
         self.latent_shard = shard
 
@@ -181,10 +209,10 @@ class ProjectedGPModel(ExactGPModel):
 
     def project_data(self, data):
         """(q x n) projected observations (projected_lmc.py:1014-1021)."""
-        Q, R, Q_orth = self.lmc_coefficients.QR()
+        Q, R, Q_orth = self.lmc_coefficients.QR(store=True)
         QtY = Q.T @ data.T                                               # q x n
         # ProjectedLMCmll needs |Y Q|_F^2 of the same Y and Q (scalar-B discarded-noise term, :1215): keep the product
-        object.__setattr__(self, "_QtY_cache", (Q, data, QtY) if self.training else None)
+        _cache_set(self, "QtY", (Q, data, QtY) if (self.training and torch.is_grad_enabled()) else None)
         out = torch.linalg.solve_triangular(R, QtY, upper=True)
         if hasattr(self, "M"):
             out = out + self.projected_noise()[:, None] * self.M @ Q_orth.T @ data.T
@@ -385,15 +413,15 @@ class ProjectedLMCmll(ExactMarginalLogLikelihood):
 
         p, q = model.n_tasks, model.n_latents
         self.proj_term_list = [0] * 3
-        Q, R, Q_orth = model.lmc_coefficients.QR()
+        Q, R, Q_orth = model.lmc_coefficients.QR(reuse=True)
         model.lmc_coefficients.drop_qr_cache()              # last use in a training step: do not outlive the graph
         if not hasattr(model, 'M') and model.scalar_B:
             if model.log_B_tilde.numel() > 0:
                 lb = model.log_B_tilde
                 root_diag = lb / 2
-                cached = getattr(model, "_QtY_cache", None)              # Q^T Y^T of project_data, same Q and Y
+                cached = _cache_get(model, "QtY")                        # Q^T Y^T of project_data, same Q and Y
                 YQ = cached[2] if (cached is not None and cached[0] is Q and cached[1] is target) else target @ Q
-                object.__setattr__(model, "_QtY_cache", None)
+                _cache_set(model, "QtY", None)
                 self.proj_term_list[1] = -0.5 * torch.exp(-lb[0]) * (model.Y_squared_norm - YQ.pow(2).sum()) / num_data
             else:
                 self.proj_term_list[1] = 0.

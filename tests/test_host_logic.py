@@ -221,3 +221,78 @@ def test_deferred_pivot_check_context_restores_the_outer_one():
         assert _engine.deferred_pivot_checks.current is outer
     assert _engine.deferred_pivot_checks.current is None
     assert outer.failed() is False and outer.first_bad is None
+
+
+# ------------------------------------------------------------------ round-2 host fixes
+def test_qr_cache_lives_only_inside_a_training_step():
+    """The shared QR of the mixing matrix is stored by project_data in training mode and nowhere else: eval-mode calls
+    and projection_matrix factor afresh (in-place edits through H.data are seen), and a model that has projected data
+    still deep-copies (the step-local caches hold non-leaf tensors and are excluded from the module state)."""
+    import copy
+    X, Y = _data()
+    m = _model(X, Y, 2, init_lmc_coeffs=True, **VARIANTS["PLMC"])
+    lmc = m.lmc_coefficients
+    m.eval()
+    m.project_data(Y)
+    m.projection_matrix()
+    from projectedlmc.projected import _cache_get
+    assert _cache_get(lmc, "qr") is None and _cache_get(m, "QtY") is None
+    T0 = m.projection_matrix().detach().clone()
+    with torch.no_grad():
+        lmc.H.data.mul_(2.0)                              # no version bump
+    assert torch.allclose(m.projection_matrix(), T0 / 2.0, atol=1e-12)
+    m.train()
+    m.project_data(Y)
+    assert _cache_get(lmc, "qr") is not None and _cache_get(m, "QtY") is not None
+    m2 = copy.deepcopy(m)                                 # used to raise: cached non-leaf tensors in the module dict
+    assert _cache_get(m2.lmc_coefficients, "qr") is None and _cache_get(m2, "QtY") is None
+    Q1, R1, _ = lmc.QR(reuse=True)
+    assert torch.equal(Q1, _cache_get(lmc, "qr")[1][:, :2])
+    lmc.drop_qr_cache()
+    with torch.no_grad():
+        m.project_data(Y)
+    assert _cache_get(lmc, "qr") is None                  # no graph, nothing stored
+
+
+def test_latent_shard_validation():
+    X, Y = _data()
+    m = _model(X, Y, 2, **VARIANTS["PLMC_fast"])
+    m.set_latent_shard((1, 2))
+    assert m.latent_ids == [1]
+    with pytest.raises(ValueError, match="ranks for 2 latent"):
+        m.set_latent_shard((0, 3))                        # a rank with no latent would block the all-reduce
+    with pytest.raises(ValueError, match="0 <= rank < world"):
+        m.set_latent_shard((2, 2))
+
+
+def test_workspace_eviction_waits_for_the_gradient_stream(monkeypatch):
+    """A workspace dropped from the cache (eviction or free_workspaces) may still be read by the fused K^-1 + gradient
+    kernel on the gradient stream: the releasing stream must wait for its `pending` event first."""
+    from projectedlmc import _engine
+
+    class FakeStream:
+        def __init__(self):
+            self.waited = []
+
+        def wait_event(self, e):
+            self.waited.append(e)
+
+    class FakeWs:
+        def __init__(self, ev):
+            self.pending, self.device = ev, torch.device("cpu")
+
+    st = FakeStream()
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: st)
+    monkeypatch.setattr(_engine, "_ws_cache", {"a": FakeWs("ev_a"), "b": FakeWs(None), "c": FakeWs("ev_c")})
+    _engine.free_workspaces()
+    assert st.waited == ["ev_a", "ev_c"] and _engine._ws_cache == {}
+
+
+def test_stream_handle_carries_its_device():
+    from projectedlmc import _hip
+
+    class S:
+        cuda_stream = 1234
+
+    h = _hip.stream_handle(S(), torch.device("cuda", 1))
+    assert isinstance(h, ctypes.c_void_p) and h.value == 1234 and h.device.index == 1
