@@ -72,6 +72,23 @@ def _worker(rank, world, port, q, ret):
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     ok = ok and all(torch.equal(gathered[0], t) for t in gathered)
+
+    # sharded PREDICTION (projected_lmc.py:1144,1152): every rank computes the posterior of its own latents, one
+    # all-reduce of the (2, n*, p) partial mean / variance sums forms the task-space posterior on every rank
+    def fake_posterior(kind, X_, ell, oscale, noise, y, Xs_, full_cov=False):
+        k, nu = kinds[kind]
+        mu, cov = gm.exact_gp_posterior(k, X_, ell, noise, y, Xs_, oscale, nu)
+        return mu, (cov if full_cov else torch.diagonal(cov, dim1=-2, dim2=-1))
+    _engine.exact_posterior = fake_posterior
+    Xs = 2 * torch.rand(9, d, generator=torch.Generator().manual_seed(5)) - 1
+    m0.eval(); m1.eval()
+    with torch.no_grad():
+        for pa, pb in zip(m0.parameters(), m1.parameters()):          # same parameters on both models
+            pa.copy_(pb)
+        ref = m0(Xs)
+        got = m1(Xs)
+    ok = ok and torch.allclose(got.mean, ref.mean, rtol=1e-10, atol=1e-12)
+    ok = ok and torch.allclose(got.variance, ref.variance, rtol=1e-9, atol=1e-12)
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
