@@ -120,6 +120,16 @@ int plmc_wt_matvec_f64(const double *W, int64_t n_pad, int64_t ldw, int64_t stri
                        double *alpha, int q, void *stream);
 
 /*
+ * kinv_diag = diag(Khat^-1) = column sums of squares of W (q x n_pad): the leave-one-out variances
+ * sigma2_i = 1 / [Khat^-1]_ii of `MultitaskGPModel.compute_loo` (:642-656) on the dense (n p) x (n p) system, where
+ * the fused gradient kernel (single ARD kernel per matrix) does not apply.  HBM-bound, reads W once.
+ */
+int plmc_w_diag_f32(const float *W, int64_t n_pad, int64_t ldw, int64_t strideW, float *kinv_diag, int q,
+                    void *stream);
+int plmc_w_diag_f64(const double *W, int64_t n_pad, int64_t ldw, int64_t strideW, double *kinv_diag, int q,
+                    void *stream);
+
+/*
  * Fused K^-1 = W^T W (MFMA) + analytic MLL gradient reduction: for every upper tile of K^-1 the
  * epilogue forms (alpha alpha^T - K^-1) o dKhat/dtheta from X staged in LDS and reduces it.
  *   grad[latent][0..d-1] = d logp / d ell_k,  [d] = d/d noise,  [d+1] = d/d oscale   (double)

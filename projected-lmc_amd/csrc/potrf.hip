@@ -290,6 +290,39 @@ __global__ __launch_bounds__(WTMV_NT) void k_wt_matvec(const T *__restrict__ W, 
   }
 }
 
+// kd[i] = sum_{l >= block(i)} W[l][i]^2 = [Khat^-1]_ii (Khat^-1 = W^T W).  Same walk as k_wt_matvec (HBM-bound: reads the
+// lower triangle of W once); fp64 accumulation.  grid (n_pad / 128, q).
+template <typename T>
+__global__ __launch_bounds__(WTMV_NT) void k_w_diag(const T *__restrict__ W, int64_t n_pad, int64_t ldw, int64_t strideW,
+                                                    T *__restrict__ kd) {
+  using vec_t = typename Traits<T>::vec_t;
+  constexpr int EPV = Traits<T>::EPV;
+  constexpr int LPR = 128 / EPV;
+  constexpr int NRG = WTMV_NT / LPR;
+  __shared__ double red[NRG][NB];
+  const int lat = blockIdx.y;
+  const int cl = (threadIdx.x % LPR) * EPV, rg = threadIdx.x / LPR;
+  const int64_t col0 = (int64_t)blockIdx.x * NB;
+  const T *Wl = W + (int64_t)lat * strideW + col0 + cl;
+  double s[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) s[e] = 0.0;
+  for (int64_t l = col0 + rg; l < n_pad; l += NRG) {
+    const vec_t v = *reinterpret_cast<const vec_t *>(Wl + l * ldw);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) s[e] += (double)v[e] * (double)v[e];
+  }
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) red[rg][cl + e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < NB) {
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < NRG; ++g) t += red[g][threadIdx.x];
+    kd[(int64_t)lat * n_pad + col0 + threadIdx.x] = (T)t;
+  }
+}
+
 // ----------------------------------------------------------------------------------------------
 template <typename T>
 int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *Vd, double *logdet, int *info,
@@ -534,6 +567,16 @@ int wt_matvec_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, cons
   return launch_status(__func__);
 }
 
+template <typename T>
+int w_diag_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, T *kinv_diag, int q, void *stream) {
+  PLMC_REQUIRE(W && kinv_diag, "null pointer");
+  PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0 && q > 0 && aligned16(W), "n_pad must be a multiple of NB");
+  ProfScope ps(PK_WTMV, (hipStream_t)stream, q * (double)n_pad * n_pad, q * ((double)n_pad * n_pad / 2) * sizeof(T));
+  hipLaunchKernelGGL(k_w_diag<T>, dim3((unsigned)(n_pad / NB), q), dim3(WTMV_NT), 0, (hipStream_t)stream, W, n_pad, ldw, strideW,
+                     kinv_diag);
+  return launch_status(__func__);
+}
+
 }  // namespace plmc
 
 extern "C" {
@@ -563,5 +606,11 @@ int plmc_wt_matvec_f32(const float *W, int64_t n_pad, int64_t ldw, int64_t strid
 int plmc_wt_matvec_f64(const double *W, int64_t n_pad, int64_t ldw, int64_t strideW, const double *z, double *alpha,
                        int q, void *stream) {
   return plmc::wt_matvec_impl<double>(W, n_pad, ldw, strideW, z, alpha, q, stream);
+}
+int plmc_w_diag_f32(const float *W, int64_t n_pad, int64_t ldw, int64_t strideW, float *kinv_diag, int q, void *stream) {
+  return plmc::w_diag_impl<float>(W, n_pad, ldw, strideW, kinv_diag, q, stream);
+}
+int plmc_w_diag_f64(const double *W, int64_t n_pad, int64_t ldw, int64_t strideW, double *kinv_diag, int q, void *stream) {
+  return plmc::w_diag_impl<double>(W, n_pad, ldw, strideW, kinv_diag, q, stream);
 }
 }

@@ -137,3 +137,25 @@ def lmc_posterior(kind, X, ell, oscale, B, Sigma, y, Xs):
     prior_var = (os_[:, None] * torch.diagonal(Bc, dim1=-2, dim2=-1)).sum(0)            # k(x,x) = 1
     var = prior_var[None, :] - (V * V).sum(0).reshape(ns, p)
     return mean, var
+
+
+def lmc_loo(kind, X, ell, oscale, B, Sigma, y):
+    """Leave-one-out moments of the dense LMC / ICM system (MultitaskGPModel.compute_loo, projected_lmc.py:642-656):
+    sigma2_i = 1 / [K_full^-1]_ii,  (y - mu_loo)_i = [K_full^-1 y]_i sigma2_i,  both flat (n p,), from the factorisation
+    the MLL uses: W = U^-T gives alpha = W^T (U^-T y) and diag(K^-1) = column sums of squares of W (plmc_w_diag)."""
+    _hip.require_device(X, ell, B, Sigma, y)
+    L = _hip.lib()
+    dt, dev = y.dtype, y.device
+    n, d = X.shape
+    p = B.shape[-1]
+    N = n * p
+    Xc, ellc, osc, Bc, Sc, yc = (_contig(t, dt) for t in (X, ell, oscale, B, Sigma, y))
+    ws = _workspace(N, 1, dt, dev, True)
+    _factorize(kind, Xc, ellc, osc, Bc, Sc, yc.reshape(1, 1, N), ws, p)
+    st = _hip.stream_ptr(dev)
+    L.call("plmc_extract_col", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, 0, _hip.ptr(ws.z), _hip.ptr(ws.quad), 1, st)
+    L.call("plmc_wt_matvec", dt, _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.z), _hip.ptr(ws.alpha), 1, st)
+    kd = torch.empty(1, ws.n_pad, dtype=dt, device=dev)
+    L.call("plmc_w_diag", dt, _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(kd), 1, st)
+    sigma2 = 1.0 / kd[0, :N]
+    return sigma2, ws.alpha[0, :N] * sigma2

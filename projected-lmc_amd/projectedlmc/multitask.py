@@ -101,6 +101,19 @@ class MultitaskGPModel(ExactGPModel):
                                               lazy.B.detach(), Sigma.detach(), resid.detach(), sel(x))
         return MultitaskMultivariateNormal(mean + self.mean_module(x), _DiagonalTaskCovariance(var))
 
+    def compute_loo(self, output=None):
+        """Leave-one-out variances and residuals of the dense multitask system, shaped like train_y (n x p)
+        (projected_lmc.py:642-656: K = likelihood(output), sigma2 = 1 / diag(K^-1), y - mu_loo = K^-1 (y - m) sigma2).
+        `output` is accepted for signature compatibility; the covariance is rebuilt from the current parameters."""
+        tx = self.train_inputs[0]
+        lazy = self.covar_module(tx)
+        Sigma = self.likelihood.task_noise_matrix(lazy.B.dtype)
+        resid = (self.train_targets - self.mean_module(tx)).reshape(-1)
+        with torch.no_grad():
+            s2, r = _lmc_engine.lmc_loo(lazy.kind, lazy.x, lazy.ell.detach(), None if lazy.oscale is None else lazy.oscale.detach(),
+                                        lazy.B.detach(), Sigma.detach(), resid.detach())
+        return s2.reshape(self.train_targets.shape), r.reshape(self.train_targets.shape)
+
     def compute_var(self, x):
         """Predictive variance incl. likelihood noise, clamped at 1e-6 (projected_lmc.py:591-640;
         the reference evaluates it through a Kronecker eigen-decomposition, ICM only)."""

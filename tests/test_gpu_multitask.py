@@ -107,3 +107,58 @@ def test_exact_lmc_fp32_and_dense_evaluate(plmc):
     dense = lik(model(X.float().to(DEV))).covariance_matrix.cpu().double()
     C = ld.lmc_covariance("rbf", X, ell.detach(), B.detach(), S.detach())
     assert torch.allclose(dense, C, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("model_type", ["ICM", "LMC"])
+def test_multitask_compute_loo(plmc, model_type):
+    """MultitaskGPModel.compute_loo (projected_lmc.py:642-656) against the dense formulas on the oracle's covariance:
+    sigma2 = 1 / diag(K^-1), y - mu_loo = K^-1 (y - m) sigma2, reshaped to (n, p)."""
+    n, d, p, q = 90, 3, 4, 2
+    X, Y = _data(n, d, p, seed=21)
+    torch.manual_seed(4)
+    lik = plmc.MultitaskGaussianLikelihood(num_tasks=p, rank=0)
+    model = plmc.MultitaskGPModel(X, Y, lik, n_tasks=p, n_latents=q, model_type=model_type, init_lmc_coeffs=True,
+                                  mean_type=plmc.ConstantMean, kernel_type=plmc.MaternKernel)
+    model, lik = model.double(), lik.double()
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for prm in list(model.parameters()) + list(lik.parameters()):
+            prm.add_(0.2 * torch.randn(prm.shape, generator=g, dtype=torch.float64))
+    sd, ell, B, S, mc = _oracle_inputs(model, lik)
+    with torch.no_grad():
+        C = ld.lmc_covariance("matern", X, ell, B, S, 2.5)
+        Kinv = torch.linalg.inv(C)
+        s2_ref = 1.0 / torch.diagonal(Kinv)
+        r_ref = (Kinv @ (Y - mc.reshape(1, p)).reshape(-1)) * s2_ref
+    model, lik = model.to(DEV), lik.to(DEV)
+    s2, r = model.compute_loo()
+    assert s2.shape == (n, p) and r.shape == (n, p)
+    assert torch.allclose(s2.cpu().reshape(-1), s2_ref, rtol=1e-8, atol=1e-12)
+    assert torch.allclose(r.cpu().reshape(-1), r_ref, rtol=1e-7, atol=1e-10)
+
+
+def test_icm_compute_var(plmc):
+    """MultitaskGPModel.compute_var (projected_lmc.py:591-640, ICM only): predictive variance including the task
+    noise, clamped at 1e-6 -- the reference gets it from a Kronecker eigen-decomposition, here from the augmented
+    factorisation; both equal dense conditioning.  LMC models raise, as in the reference (:600-601)."""
+    n, d, p, q = 80, 2, 3, 2
+    X, Y = _data(n, d, p, seed=31)
+    torch.manual_seed(6)
+    lik = plmc.MultitaskGaussianLikelihood(num_tasks=p, rank=0)
+    model = plmc.MultitaskGPModel(X, Y, lik, n_tasks=p, n_latents=q, model_type="ICM", init_lmc_coeffs=True,
+                                  mean_type=plmc.ConstantMean, kernel_type=plmc.RBFKernel)
+    model, lik = model.double(), lik.double()
+    sd, ell, B, S, mc = _oracle_inputs(model, lik)
+    Xs = 2 * torch.rand(11, d, dtype=torch.float64) - 1
+    with torch.no_grad():
+        _, var = ld.lmc_posterior("rbf", X, Y, Xs, ell, B, S, mean_const=mc, nu=2.5)
+        ref = torch.clamp(var + torch.diagonal(S)[None, :], min=1e-6)
+    model, lik = model.to(DEV), lik.to(DEV)
+    model.train()
+    got = model.compute_var(Xs.to(DEV))
+    assert model.training                                   # mode restored
+    assert got.shape == (11, p) and torch.allclose(got.cpu(), ref, rtol=1e-7, atol=1e-10)
+    lmc = plmc.MultitaskGPModel(X, Y, plmc.MultitaskGaussianLikelihood(num_tasks=p, rank=0), n_tasks=p, n_latents=q,
+                                model_type="LMC", kernel_type=plmc.RBFKernel).double().to(DEV)
+    with pytest.raises(ValueError, match="only available for ICM"):
+        lmc.compute_var(Xs.to(DEV))
