@@ -1,4 +1,5 @@
-"""Mean functions the BASELINE configs use (ZeroMean / ConstantMean / MultitaskMean), with the
+"""Mean functions: ZeroMean / ConstantMean / MultitaskMean (what the BASELINE configs use) and the reference's own
+LinearMean / PolynomialMean (projected_lmc.py:38-81), with the
 constructor surface the reference relies on: `mean_type(input_size=dim, batch_shape=...)`
 (projected_lmc.py:298,739,752) and `MultitaskMean(base, num_tasks=p)` (:460).
 [gpytorch-knowledge] ConstantMean holds `raw_constant` (batch_shape), initialised to 0."""
@@ -33,6 +34,53 @@ class ConstantMean(Mean):
     def forward(self, x):
         c = self.raw_constant.to(x.dtype)
         return c.unsqueeze(-1).expand(*self.batch_shape, x.shape[-2])
+
+
+class LinearMean(Mean):
+    """m(x) = x w + b with weights (*batch, d, 1) and bias (*batch, 1), randn-initialised (projected_lmc.py:65-81)."""
+
+    def __init__(self, input_size, batch_shape=torch.Size(), bias=True, **kwargs):
+        super().__init__()
+        self.batch_shape = torch.Size(batch_shape)
+        self.register_parameter("weights", torch.nn.Parameter(torch.randn(*self.batch_shape, input_size, 1)))
+        if bias:
+            self.register_parameter("bias", torch.nn.Parameter(torch.randn(*self.batch_shape, 1)))
+        else:
+            self.bias = None
+
+    def forward(self, x):
+        res = x.matmul(self.weights.to(x.dtype)).squeeze(-1)
+        if self.bias is not None:
+            res = res + self.bias.to(x.dtype)
+        return res
+
+    def basis_matrix(self, x):
+        return torch.hstack([x, torch.ones((len(x), 1), device=x.device, dtype=x.dtype)])
+
+
+class PolynomialMean(Mean):
+    """m(x) = sum_{i=1..degree} (x ** i) w_i + b (projected_lmc.py:38-63; like the reference, a `weights_0` parameter is
+    registered and never used)."""
+
+    def __init__(self, input_size, batch_shape=torch.Size(), bias=True, degree=3, **kwargs):
+        super().__init__()
+        self.batch_shape = torch.Size(batch_shape)
+        for i in range(degree + 1):
+            self.register_parameter("weights_{0}".format(i),
+                                    torch.nn.Parameter(torch.randn(*self.batch_shape, input_size, 1)))
+        if bias:
+            self.register_parameter("bias", torch.nn.Parameter(torch.randn(*self.batch_shape, 1)))
+        else:
+            self.bias = None
+        self.degree = degree
+
+    def forward(self, x):
+        res = 0
+        for i in range(1, self.degree + 1):
+            res = res + (x ** i).matmul(getattr(self, "weights_{0}".format(i)).to(x.dtype)).squeeze(-1)
+        if self.bias is not None:
+            res = res + self.bias.to(x.dtype)
+        return res
 
 
 class MultitaskMean(Mean):

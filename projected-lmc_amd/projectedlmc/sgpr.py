@@ -10,12 +10,14 @@ predictive moments use Q for all blocks.
 
 HIP path: A = L^-1 K_zx (L L^T = K_zz) is one augmented sweep of the library
 (`_var_engine.WhitenedInterp`, including the adjoint w.r.t. inducing points and lengthscales); what
-remains is m x m algebra (B = I + A A^T / sigma^2 and its Cholesky factor), done in torch.
+remains is the m x m Woodbury matrix B = I + A A^T / sigma^2: its quadratic form, log-determinant and half-solves go
+through the same blocked sweep (`_dense.py`), with the closed-form adjoint -- no library factorisation on this path.
 """
 import math
 
 import torch
 
+from . import _dense
 from . import _var_engine
 from .kernels import Kernel
 
@@ -84,12 +86,11 @@ class LazySgprKernel:
         s = self.noise.reshape(q, 1, 1).to(A.dtype)
         eye = torch.eye(m, dtype=A.dtype, device=A.device)
         Bm = eye + (A @ A.transpose(-1, -2)) / s
-        LB = torch.linalg.cholesky(Bm)
-        Ay = (A @ y.unsqueeze(-1))                                     # (q,m,1)
-        c = torch.linalg.solve_triangular(LB, Ay, upper=False).squeeze(-1)
+        Ay = (A @ y.unsqueeze(-1)).squeeze(-1)                         # (q,m)
+        cc, logdetB = _dense.spd_quad_logdet(Bm, Ay)                   # (A y)^T B^-1 (A y), log det B
         s1 = s.reshape(q)
-        quad = ((y * y).sum(-1) - (c * c).sum(-1) / s1) / s1
-        logdet = n * torch.log(s1) + 2.0 * torch.log(torch.diagonal(LB, dim1=-2, dim2=-1)).sum(-1)
+        quad = ((y * y).sum(-1) - cc / s1) / s1
+        logdet = n * torch.log(s1) + logdetB
         os_ = torch.ones(q, dtype=A.dtype, device=A.device) if self.oscale is None else self.oscale
         self.owner._added_loss = -0.5 * (n * os_ - (A * A).sum((-2, -1))) / s1
         return -0.5 * (quad + logdet + n * math.log(2.0 * math.pi))
@@ -101,9 +102,8 @@ class LazySgprKernel:
         q, m, n = A.shape
         s = self.noise.reshape(q, 1, 1).to(A.dtype)
         eye = torch.eye(m, dtype=A.dtype, device=A.device)
-        LB = torch.linalg.cholesky(eye + (A @ A.transpose(-1, -2)) / s)
-        c = torch.linalg.solve_triangular(LB, A @ y.unsqueeze(-1), upper=False)           # (q,m,1)
-        Vs = torch.linalg.solve_triangular(LB, As, upper=False)                           # (q,m,ns)
+        sol = _dense.spd_half_solve(eye + (A @ A.transpose(-1, -2)) / s, torch.cat([A @ y.unsqueeze(-1), As], -1))
+        c, Vs = sol[..., :1], sol[..., 1:]                                                # L_B^-1 [A y | A*]
         mean = (Vs.transpose(-1, -2) @ c).squeeze(-1) / s.reshape(q, 1)
         var = (Vs * Vs).sum(-2)
         return mean, var

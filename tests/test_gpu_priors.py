@@ -71,3 +71,40 @@ def test_kernel_cond():
     model.likelihood = model.likelihood.to(DEV)
     got = model.kernel_cond()
     assert abs(float(got) - float(ref)) <= 1e-7 * float(ref)
+
+
+@pytest.mark.parametrize("mean", ["LinearMean", "PolynomialMean"])
+def test_reference_mean_functions(mean):
+    """LinearMean / PolynomialMean of the reference (projected_lmc.py:38-81) on the exact-GP path: MLL and the
+    gradient of every mean / kernel / noise parameter against the dense oracle; basis_matrix of LinearMean."""
+    import projectedlmc as plmc
+    from oracle import gp_math as gm
+    g = torch.Generator().manual_seed(0)
+    n, d = 140, 3
+    X = 2 * torch.rand(n, d, generator=g, dtype=torch.float64) - 1
+    y = torch.randn(n, generator=g, dtype=torch.float64)
+    torch.manual_seed(3)
+    lik = plmc.GaussianLikelihood()
+    model = plmc.ExactGPModel(X, y, lik, mean_type=getattr(plmc, mean), kernel_type=plmc.MaternKernel).double()
+    lik = lik.double()
+    leaves = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    if mean == "LinearMean":
+        m = (X @ leaves["mean_module.weights"].reshape(d, 1)).reshape(-1) + leaves["mean_module.bias"].reshape(())
+        assert torch.equal(model.mean_module.basis_matrix(X), torch.hstack([X, torch.ones(n, 1, dtype=torch.float64)]))
+    else:
+        m = sum(((X ** i) @ leaves["mean_module.weights_%d" % i].reshape(d, 1)).reshape(-1) for i in (1, 2, 3))
+        m = m + leaves["mean_module.bias"].reshape(())
+    ell = gm.softplus(leaves["covar_module.raw_lengthscale"]).reshape(1, -1)
+    noise = gm.softplus(leaves["likelihood.noise_covar.raw_noise"]).reshape(1) + 1e-4
+    ref = gm.exact_latent_log_prob("matern", X, ell, noise, (y - m).reshape(1, -1), None, 2.5).sum() / n
+    ref.backward()
+    model, lik = model.to("cuda:0"), lik.to("cuda:0")
+    model.train(); lik.train()
+    out = plmc.ExactMarginalLogLikelihood(lik, model)(model(X.to("cuda:0")), y.to("cuda:0")).sum()
+    out.backward()
+    assert abs(float(out.detach()) - float(ref)) < 1e-9 * abs(float(ref))
+    for name, prm in model.named_parameters():
+        if leaves[name].grad is None:                       # weights_0 of PolynomialMean is never used (as in the reference)
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0
+            continue
+        assert torch.allclose(prm.grad.cpu(), leaves[name].grad, rtol=1e-5, atol=1e-9), name
