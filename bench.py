@@ -59,6 +59,56 @@ def make_data(n, d, p, q, seed=0, dtype=torch.float32):
     return X.to(dtype), Y.to(dtype)
 
 
+def build_key():
+    """sha256 over the library sources: PMC traffic numbers under profiles/ are only valid for the build they were
+    measured on (tools/pmc_aggregate.py stores the same key)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "projected-lmc_amd", "csrc")
+    for f in sorted(os.listdir(csrc)) + [os.path.join("..", "..", "include", "plmc.h")]:
+        path = os.path.join(csrc, f)
+        if os.path.isfile(path) and f.endswith((".hip", ".hpp", ".h")):
+            h.update(f.encode() + b"\0" + open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kname):
+    """HBM bytes per launch of `kname` from the newest profiles/rNN_pmc_traffic.json measured on THIS build, else None."""
+    import glob
+    key = build_key()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except Exception:
+            continue
+        if pmc.get("build_key") == key and kname in pmc.get("kernels", {}):
+            return pmc["kernels"][kname]["hbm_bytes_corrected"], os.path.relpath(path, ROOT)
+    return None, None
+
+
+def live_traffic(kname, latents):
+    """Two rocprofv3 --pmc child runs of this script (FETCH_SIZE, WRITE_SIZE: separate passes, --kernel-trace only), aggregated
+    as tools/pmc_aggregate.py does (hbm bytes = 2 * FETCH + WRITE on gfx950, MI355X_MICROARCH.md).  Returns bytes per launch or None."""
+    import csv, glob, shutil, subprocess, tempfile
+    tot = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="plmc_pmc_")
+        try:
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", tmp, "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--latents", str(latents), "--no-cpu-baseline", "--no-prof"]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=240, check=True)
+            files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+            vals = [float(r["Counter_Value"]) * 1024.0 for r in csv.DictReader(open(files[0]))
+                    if r.get("Counter_Name") == ctr and kname in r["Kernel_Name"].replace("plmc::", "")]
+            tot[ctr] = sum(vals) / max(1, len(vals))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]
+
+
 def host_cores():
     """Cores this process may actually use: min(affinity, cgroup CPU quota).  (On the GPU box
     os.cpu_count() reports the whole host while the container is limited by cpu.max.)"""
@@ -70,6 +120,14 @@ def host_cores():
     except Exception:
         pass
     return n
+
+
+def oracle_latent(X, ell, noise, ytil):
+    """fp64 oracle of one latent at full size: (logp, gradient vector over lengthscales, noise and every y entry)."""
+    from oracle import cpu_step
+    torch.set_num_threads(host_cores())
+    lp, ge, gn, gy = cpu_step.latent_step("matern", X.double(), ell.double(), noise.double(), ytil.double(), nu=2.5)
+    return float(lp), torch.cat([ge.reshape(-1), gn.reshape(-1), gy.reshape(-1)])
 
 
 def cpu_baseline(X, Y, model_cpu_state, n_latents, budget_latents=4):
@@ -87,13 +145,10 @@ def cpu_baseline(X, Y, model_cpu_state, n_latents, budget_latents=4):
         lp, *_ = cpu_step.latent_step("matern", X, ell[j], noise[j], ytil[j], nu=2.5)
         ts.append(time.time() - t0)
     t = sum(ts[1:]) / len(ts[1:]) if len(ts) > 1 else ts[0]          # mean over the sampled latents (~10 s of CPU work)
-    # fp64 value and analytic gradient of latent 0 for the relative-error checks
-    lp64, ge64, gn64, _ = cpu_step.latent_step("matern", X.double(), ell[0].double(), noise[0].double(), ytil[0].double(), nu=2.5)
-    g64 = torch.cat([ge64.reshape(-1), gn64.reshape(-1)])
     return dict(value=1.0 / (n_latents * t), unit="iters/sec", cores=torch.get_num_threads(), kind="port",
                 sample="%d of %d latent exact-GP MLL+gradient evaluations at n=%d (fp32 dense Cholesky + inverse, "
                        "torch CPU), scaled to the full %d-latent step; %.1f s per latent" % (
-                           budget_latents, n_latents, n, n_latents, t)), float(lp64), g64
+                           budget_latents, n_latents, n, n_latents, t))
 
 
 def main():
@@ -108,6 +163,8 @@ def main():
     ap.add_argument("--variant", default="PLMC_fast", choices=["PLMC_fast", "PLMC"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic live (two rocprofv3 --pmc child runs) "
+                                                      "when no profile of this build is committed")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,29 +226,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # per-latent log-prob at the initial parameters (untimed; for the rel-err check vs the fp64 oracle)
+    # Accuracy checkpoints (untimed): the HIP log-prob and its gradient w.r.t. EVERY parameter of a latent GP
+    # (lengthscales, noise, all n projected targets) against the fp64 oracle at full size -- latent 0 at the initial
+    # parameters, latents 0 and q-1 after 5 optimiser steps.  The mixing-matrix / noise-model parameters
+    # sit behind d logp / d y~ through the same torch autograd on both sides.
     from projectedlmc import _engine
-    with torch.no_grad():
-        lp_init = _engine.exact_latent_log_prob("matern52", Xd, cpu_state[0].to(dev), None, cpu_state[1].to(dev),
-                                                cpu_state[2].to(dev))
-        lp0_gpu = float(lp_init[0]) if rank == 0 else 0.0
-    # ... and its analytic gradient for latent 0 (lengthscales, noise), same check at full size
-    g0_gpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        e0 = cpu_state[0][:1].to(dev).requires_grad_()
-        z0 = cpu_state[1][:1].to(dev).requires_grad_()
-        _engine.exact_latent_log_prob("matern52", Xd, e0, None, z0, cpu_state[2][:1].to(dev)).sum().backward()
-        g0_gpu = torch.cat([e0.grad.reshape(-1), z0.grad.reshape(-1)]).double().cpu()
+    do_checks = rank == 0 and world == 1 and not args.no_cpu_baseline
+    checkpoints = []                                    # (label, latent, ell, noise, ytil, lp_gpu, grad_gpu)
+
+    def gpu_checkpoint(label, state, latents):
+        for j in latents:
+            e = state[0][j:j + 1].to(dev).requires_grad_()
+            z = state[1][j:j + 1].to(dev).requires_grad_()
+            yt = state[2][j:j + 1].to(dev).requires_grad_()
+            lp = _engine.exact_latent_log_prob("matern52", Xd, e, None, z, yt)
+            lp.sum().backward()
+            g = torch.cat([e.grad.reshape(-1), z.grad.reshape(-1), yt.grad.reshape(-1)]).double().cpu()
+            checkpoints.append((label, j, state[0][j].cpu(), state[1][j].cpu(), state[2][j].cpu(), float(lp), g))
+
+    if do_checks:
+        gpu_checkpoint("initial parameters", cpu_state, [0])
+
     def note(msg):
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
     note("warm-up (%d steps)" % args.warmup)
     first_loss = None
+    n_check = min(5, args.warmup)
     for i in range(args.warmup):
         l0 = step()
         if first_loss is None:
             first_loss = float(l0)
+        if do_checks and i + 1 == n_check:
+            with torch.no_grad():
+                st5 = (model.covar_module.lengthscale.reshape(q, d).clone(), model.projected_noise().clone(),
+                       model.project_data(Yd).clone())
+            gpu_checkpoint("after %d optimiser steps" % n_check, st5, sorted({0, q - 1}))
+            model.train()
     # Inside the timed region only the two MFMA-heavy kernel classes (and the whole sweep) are bracketed by
     # HIP events: a bracket costs ~10 us of stream time, which on the ~200 short chain kernels of a step
     # would distort the very step time being measured.  The full per-kernel table comes from extra untimed
@@ -217,12 +289,11 @@ def main():
         table = _hip.prof_collect()
         # the same kernels with the look-ahead off (one stream, nothing overlaps): per-kernel rates undiluted
         # by concurrent launches -- reported beside the in-situ roofline, never as the step time
-        os.environ["PLMC_SERIAL"] = "1"
-        for i in range(2):
-            step()
-        fence()
-        iso = _hip.prof_collect()
-        del os.environ["PLMC_SERIAL"]
+        with _hip.knob("PLMC_SERIAL", "1"):
+            for i in range(2):
+                step()
+            fence()
+            iso = _hip.prof_collect()
         _hip.prof_enable(False)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -240,6 +311,9 @@ def main():
                        "n_points": n, "n_dim": d, "n_tasks": p, "n_latents": q, "parallelism": "latent-shard x%d" % world},
             "final_loss": float(last),
         }
+        if world > 1:
+            res["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                  "collective": "one fused all-reduce (sum) of [loss share | all parameter gradients] per step"}
         # ---- roofline of the dominant kernel (largest share of HIP-event time in the timed region)
         if stats:
             sweep = stats.pop("sweep_total", None)          # wall time of plmc_potrf on the main stream
@@ -248,8 +322,13 @@ def main():
             s = mf[dom]
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS["f32"]
+            try:
+                peak_meas = _hip.mfma_rate(torch.float32, dev)    # bare v_mfma_f32_16x16x4_f32 stream on this device, now
+            except Exception:
+                peak_meas = None
             res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": None,
+                               "frac": ach / peak, "traffic": None, "peak_measured": peak_meas,
+                               "frac_of_measured_peak": (ach / peak_meas) if peak_meas else None,
                                "avg_launch_ms": s["ms"] / s["launches"], "launches": s["launches"],
                                "flops_per_launch": s["flops"] / s["launches"]}
             if dom in iso and iso[dom]["ms"] > 0:
@@ -258,18 +337,20 @@ def main():
                                                "note": "same kernel, look-ahead off (PLMC_SERIAL=1, 2 untimed steps): no "
                                                        "concurrent launches share the GPU; `achieved` above is in situ, "
                                                        "where the chain + head run beside this kernel"}
-            # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE cannot be read from inside
-            # the process: they come from the committed rocprofv3 --pmc passes of this same command)
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                kname = {"k_trail": "k_update<float, 0, 4>", "k_trail_head": "k_update<float, 2, 4>", "k_kinv_grad": "k_kinv_grad<float, 8>"}.get(dom, dom + "<float>")
-                if world == 1 and kname in pmc["kernels"]:
-                    res["roofline"]["traffic"] = pmc["kernels"][kname]["hbm_bytes_corrected"]
-                    res["roofline"]["traffic_note"] = ("bytes/launch, (2*FETCH_SIZE+WRITE_SIZE) from profiles/"
-                                                       "r01_pmc_traffic.json; algorithmic tile traffic/launch = %.3g"
-                                                       % (s["bytes"] / s["launches"]))
-            except Exception:
-                pass
+            # HBM bytes per launch from the PMC counters.  They cannot be read from inside the process: they come from
+            # rocprofv3 --pmc passes of this same command -- the committed ones if they were measured on THIS build
+            # (build key over the library sources), else (--pmc) two child runs now, else null.
+            kname = {"k_trail": "k_update<float, 0, 4>", "k_trail_head": "k_update<float, 2, 4>",
+                     "k_kinv_grad": "k_kinv_grad<float, 8>", "k_gpanel": "k_gpanel_rows<float>"}.get(dom, dom + "<float>")
+            if world == 1:
+                tr, src = committed_traffic(kname)
+                if tr is None and args.pmc:
+                    tr, src = live_traffic(kname, q), "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs"
+                res["roofline"]["traffic"] = tr
+                res["roofline"]["traffic_note"] = (
+                    "bytes/launch, 2*FETCH_SIZE + WRITE_SIZE (%s, build %s); algorithmic tile traffic/launch = %.3g"
+                    % (src, build_key(), s["bytes"] / s["launches"]) if tr is not None else
+                    "no PMC profile of build %s under profiles/ (run tools/collect_profiles.sh or bench.py --pmc)" % build_key())
             # per-kernel table: every class bracketed, from the untimed steps after the timed region
             table.pop("sweep_total", None)
             res["kernels"] = {k: {"ms_per_step": v["ms"] / table_steps, "launches_per_step": v["launches"] / table_steps,
@@ -291,15 +372,23 @@ def main():
         note("%.2f ms/step on %d GPU(s)" % (1e3 * elapsed / args.steps, world))
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle on %d host cores (bounded sample: 4 of %d latents) ..." % (host_cores(), q))
-            cb, lp_cpu, g_cpu = cpu_baseline(X, Y, cpu_state, q)
+            cb = cpu_baseline(X, Y, cpu_state, q)
             res["cpu_baseline"] = cb
             res["speedup_vs_cpu"] = its / cb["value"]
-            res["loglik_rel_err"] = abs(lp0_gpu - lp_cpu) / abs(lp_cpu)
-            res["loglik_check"] = "latent 0 log N(y~;0,K+s2 I) at initial parameters: fp32 HIP %.6f vs fp64 oracle %.6f" % (lp0_gpu, lp_cpu)
-            if g0_gpu is not None:
-                res["grad_rel_err"] = float((g0_gpu - g_cpu).norm() / g_cpu.norm())
-                res["grad_check"] = ("latent 0 d logp / d(lengthscales, noise) at initial parameters, |HIP fp32 - fp64 oracle| / "
-                                     "|fp64 oracle| over the %d components" % g_cpu.numel())
+            note("fp64 oracle at the %d accuracy checkpoints ..." % len(checkpoints))
+            checks = []
+            for label, j, e, z, yt, lp_gpu, g_gpu in checkpoints:
+                lp_cpu, g_cpu = oracle_latent(X, e, z, yt)
+                checks.append({"where": "latent %d, %s" % (j, label), "logp_hip_f32": lp_gpu, "logp_oracle_f64": lp_cpu,
+                               "loglik_rel_err": abs(lp_gpu - lp_cpu) / abs(lp_cpu),
+                               "grad_rel_err": float((g_gpu - g_cpu).norm() / g_cpu.norm()),
+                               "grad_max_abs_err_over_max": float((g_gpu - g_cpu).abs().max() / g_cpu.abs().max())})
+            res["loglik_rel_err"] = max(c["loglik_rel_err"] for c in checks)
+            res["grad_rel_err"] = max(c["grad_rel_err"] for c in checks)
+            res["accuracy_checks"] = checks
+            res["accuracy_note"] = ("log N(y~; 0, K + s2 I) of a latent GP and its gradient w.r.t. every lengthscale, the noise and "
+                                    "all n projected targets (d + 1 + n numbers), fp32 HIP vs fp64 CPU oracle at n = %d; max over the "
+                                    "checkpoints in loglik_rel_err / grad_rel_err" % n)
         res["first_loss"] = first_loss
         print(json.dumps(res))
     if world > 1:

@@ -120,6 +120,17 @@ int plmc_wt_matvec_f64(const double *W, int64_t n_pad, int64_t ldw, int64_t stri
                        double *alpha, int q, void *stream);
 
 /*
+ * Batched "TN" product on the tile engine:  C[b] (=, +=, -=) A[b]^T B[b]  with A: K x M and B: K x N, both stored
+ * K-major (row index = contraction index), C: M x N; mode 0 store / 1 add / 2 subtract.  M, N multiples of plmc_block(),
+ * K a multiple of 16 (callers pad with zeros), 16-byte aligned pointers / strides.  Replaces the torch.matmul (rocBLAS)
+ * calls of the Cholesky adjoint of the inducing-point interpolation (VariationalMultitaskGPModel :672-683, SGPR :302-303).
+ */
+int plmc_gemm_tn_f32(int mode, int M, int N, int K, const float *A, int64_t lda, int64_t strideA, const float *B,
+                     int64_t ldb, int64_t strideB, float *C, int64_t ldc, int64_t strideC, int batch, void *stream);
+int plmc_gemm_tn_f64(int mode, int M, int N, int K, const double *A, int64_t lda, int64_t strideA, const double *B,
+                     int64_t ldb, int64_t strideB, double *C, int64_t ldc, int64_t strideC, int batch, void *stream);
+
+/*
  * kinv_diag = diag(Khat^-1) = column sums of squares of W (q x n_pad): the leave-one-out variances
  * sigma2_i = 1 / [Khat^-1]_ii of `MultitaskGPModel.compute_loo` (:642-656) on the dense (n p) x (n p) system, where
  * the fused gradient kernel (single ARD kernel per matrix) does not apply.  HBM-bound, reads W once.
@@ -223,12 +234,24 @@ int plmc_qr_small_f64(const double *A, int m, int n, int64_t lda, double *Q, int
  * only (each bracket costs ~10 us of stream time, which matters on the latency-bound chain).  plmc_prof_collect() waits for the recorded
  * events, then returns per kernel class (index < plmc_prof_kernels(), name plmc_prof_name(i)):
  * total milliseconds, number of launches, and the ALGORITHMIC flops / bytes of those launches;
- * it clears the record.  This is the only process-global state in the library.
+ * it clears the record.
+ * Process-global state of the library (all of it): this profiler record; per device, two helper streams and eight
+ * ordering events of the look-ahead in plmc_potrf_* (created on first use, never destroyed).  Consequence: calls of
+ * plmc_potrf_* on the SAME device must not overlap in time from different host threads or caller streams (they would
+ * share those events); different devices are independent.  The Python layer calls from one thread per process.
+ * Dev knobs are environment variables read once per process (PLMC_HALF_TILES, PLMC_GRP, PLMC_KINV_ORDER,
+ * PLMC_SERIAL); plmc_dev_reload_knobs() re-reads them (tests and bench.py change one and reload).  They change
+ * schedules, never results.
+ * plmc_prof_mfma_rate: dense MFMA rate (TFLOP/s) of the current device measured with a bare instruction stream
+ * (v_mfma_f32_16x16x4_f32 or _f64_16x16x4_f64, 4 waves per SIMD, no memory traffic); synchronous; `sink` = caller-owned
+ * device scratch of at least 4 * CUs * 256 * sizeof(element) bytes.
  */
 int         plmc_prof_enable(int on);         /* returns the previous setting */
 int         plmc_prof_kernels(void);
 const char *plmc_prof_name(int id);
 int         plmc_prof_collect(double *ms, int64_t *launches, double *flops, double *bytes);
+int         plmc_prof_mfma_rate(int is_f64, void *sink, int64_t sink_bytes, double *tflops);
+int         plmc_dev_reload_knobs(void);
 
 #ifdef __cplusplus
 }

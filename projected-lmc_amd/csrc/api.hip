@@ -30,6 +30,21 @@ static hipEvent_t get_event() {
   return e;
 }
 
+static Knobs g_knobs;
+static bool g_knobs_loaded = false;
+static void load_knobs() {
+  const char *h = getenv("PLMC_HALF_TILES"), *g = getenv("PLMC_GRP"), *o = getenv("PLMC_KINV_ORDER");
+  g_knobs.half_tiles = h ? (atoi(h) == 1 ? 1e30 : (double)atoi(h)) : 640.0;
+  g_knobs.grp = g ? atoi(g) : 0;
+  g_knobs.serial = getenv("PLMC_SERIAL") != nullptr;
+  g_knobs.kinv_order = o ? atoi(o) : 4;
+  g_knobs_loaded = true;
+}
+const Knobs &knobs() {
+  if (!g_knobs_loaded) load_knobs();
+  return g_knobs;
+}
+
 // ---- helper stream + ordering events for the look-ahead of the blocked sweep (one per device,
 // created on first use; together with the profiler record this is all the process-global state).
 static hipStream_t g_side[64] = {nullptr};
@@ -62,6 +77,54 @@ hipEvent_t sync_event(int idx) {
   return e;
 }
 
+// Bare MFMA stream (no memory traffic): 16 independent accumulators per wave, 4 waves per SIMD -- the rate the matrix
+// cores sustain on THIS device under its current clocks; bench.py reports it beside the nominal peak.
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void k_mfma_rate(T *sink, int iters) {
+  using Tr = Traits<T>;
+  typename Tr::acc_t acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[i][r] = T(0);
+  T a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = T(1) + T(threadIdx.x & 7) * T(1e-3) + T(i); b[i] = T(0.5) - T(i) * T(1e-3); }
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = Tr::mfma(a[i >> 2], b[i & 3], acc[i]);
+  }
+  T s = T(0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  sink[(size_t)blockIdx.x * NTHREADS + threadIdx.x] = s;
+}
+
+template <typename T> static int mfma_rate_impl(void *sink, int64_t sink_bytes, double *tflops) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("plmc_prof_mfma_rate", "no device");
+  const int grid = 4 * prop.multiProcessorCount, iters = 4000;
+  if (!sink || !tflops || sink_bytes < (int64_t)grid * NTHREADS * (int64_t)sizeof(T)) return fail("plmc_prof_mfma_rate", "sink too small");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail("plmc_prof_mfma_rate", "event");
+  double best = 0.0;
+  for (int rep = 0; rep < 3; ++rep) {                 // first repetition warms the clocks up
+    (void)hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(k_mfma_rate<T>, dim3(grid), dim3(NTHREADS), 0, nullptr, (T *)sink, iters);
+    (void)hipEventRecord(e1, nullptr);
+    float ms = 0.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) break;
+    const double fl = (double)grid * (NTHREADS / 64) * (double)iters * 16.0 * 2.0 * 16 * 16 * 4;
+    if (ms > 0.f && fl / (ms * 1e-3) / 1e12 > best) best = fl / (ms * 1e-3) / 1e12;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *tflops = best;
+  return launch_status("plmc_prof_mfma_rate");
+}
+
 ProfScope::ProfScope(int id, hipStream_t st, double flops, double bytes) : idx_(-1), st_(st) {
   if (!((g_prof_mask >> id) & 1u) || g_recs.size() >= (1u << 20)) return;
   ProfRec r{id, get_event(), get_event(), flops, bytes};
@@ -87,6 +150,10 @@ int plmc_prof_enable(int on) {
   plmc::g_prof_mask = on == 0 ? 0u : (on == 1 ? all : ((unsigned)on >> 1) & all);
   return prev == 0 ? 0 : (prev == all ? 1 : (int)(prev << 1));
 }
+int plmc_prof_mfma_rate(int is_f64, void *sink, int64_t sink_bytes, double *tflops) {
+  return is_f64 ? plmc::mfma_rate_impl<double>(sink, sink_bytes, tflops) : plmc::mfma_rate_impl<float>(sink, sink_bytes, tflops);
+}
+int plmc_dev_reload_knobs(void) { plmc::load_knobs(); return 0; }
 int plmc_prof_kernels(void) { return plmc::PK_COUNT; }
 const char *plmc_prof_name(int id) { return (id >= 0 && id < plmc::PK_COUNT) ? plmc::kProfNames[id] : ""; }
 int plmc_prof_collect(double *ms, int64_t *launches, double *flops, double *bytes) {

@@ -43,6 +43,16 @@ struct ProfScope {
   hipStream_t st_;
 };
 
+// Dev knobs (environment variables), read ONCE per process on first use; plmc_dev_reload_knobs() re-reads them (the
+// tests and bench.py change a knob and reload).  None of them changes results, only schedules.
+struct Knobs {
+  double half_tiles;   // PLMC_HALF_TILES: 0 never, 1 always, N > 1 = tile-count threshold (default 640)
+  int grp;             // PLMC_GRP: fixed group size of the sweep (default 0 = 8)
+  bool serial;         // PLMC_SERIAL: one stream, no look-ahead
+  int kinv_order;      // PLMC_KINV_ORDER: tile order of the gradient kernel (0 XCD-dealt, 1 grid, 4 longest first, 5 = 4 + general epilogue)
+};
+const Knobs &knobs();
+
 hipStream_t side_stream(int which = 0);   // per-device helper streams (api.hip), which in {0, 1}; nullptr on failure
 hipEvent_t sync_event(int idx);     // per-device ordering events, idx in [0,8)
 

@@ -347,19 +347,9 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   T *const Pbulk = Ph + (int64_t)GMAX * NB * LDG;                       // panel buffer of the other columns (ld lda)
   T *const WA = with_inverse ? A + wcol0 : (T *)nullptr;                // inverse-factor columns of the factor buffer
 
-  // env knobs are dev aids; read once per process (getenv is not free and the values never change under a run)
-  struct Knobs { double hthr; int grp; bool serial; };
-  static const Knobs knobs = [] {
-    Knobs k;
-    const char *h = getenv("PLMC_HALF_TILES");          // 0 = never, 1 = always, N > 1 = tile-count threshold
-    k.hthr = h ? (atoi(h) == 1 ? 1e30 : (double)atoi(h)) : 640.0;
-    const char *g = getenv("PLMC_GRP");                 // fixed group size (1..GMAX)
-    k.grp = g ? atoi(g) : 0;
-    k.serial = getenv("PLMC_SERIAL_ALWAYS") != nullptr; // one stream for every sweep of the process
-    return k;
-  }();
-  const double hthr = knobs.hthr;
-  const bool serial = knobs.serial || getenv("PLMC_SERIAL") != nullptr;   // PLMC_SERIAL: per call (tests toggle it)
+  const Knobs &kn = knobs();                            // dev knobs: read once per process (api.hip)
+  const double hthr = kn.half_tiles;
+  const bool serial = kn.serial;
 
   auto diag = [&](int r, int g0, hipStream_t s) {
     ProfScope ps(PK_DIAG, s, q * (2.0 / 3.0) * nb3, q * 3.0 * nb * nb * esz);
@@ -450,7 +440,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // G (G + 1) / 2 tile products into every group-panel strip; the chain of a group costs ~3 G small launches.
   std::vector<int> gb;                                    // group boundaries: gb[i] .. gb[i+1]
   {
-    int big = knobs.grp > 0 ? knobs.grp : GMAX;
+    int big = kn.grp > 0 ? kn.grp : GMAX;
     if (big > GMAX) big = GMAX;
     gb.push_back(0);
     for (int r = 0; r < m;) {

@@ -331,8 +331,7 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
   // 77 -> 104 TF at n = 4096 (the same launch with every tile reading one panel pair ran no faster, so operand
   // locality is not what limits it; an XCD-dealt super-tile order was level with the grid).  Dev knob
   // PLMC_KINV_ORDER: 0 = XCD-dealt 8 x 8 super-tiles, 1 = (jb, ib, lat) grid, 5 = default order, general epilogue only.
-  const char *ord = getenv("PLMC_KINV_ORDER");
-  const int plain = ord ? atoi(ord) : 4;
+  const int plain = knobs().kinv_order;
   const dim3 grid = plain >= 4 ? dim3(q * (m * (m + 1) / 2)) : plain ? dim3(m, m, q) : dim3(xcd_tri_grid(m, q)), block(NTHREADS);
   double *part = reinterpret_cast<double *>(partials);
 #define PLMC_LAUNCH_KG(DC)                                                                                          \

@@ -78,3 +78,31 @@ def spd_half_solve(M, R):
         _load(ws, M.detach(), R.detach().transpose(-1, -2))
         _factor(ws, "spd_half_solve")
         return ws.A[:, :m, ws.n_pad:ws.n_pad + k].clone()
+
+
+def _padded(t, rows, cols):
+    q, r, c = t.shape
+    if r == rows and c == cols and t.is_contiguous():
+        return t
+    out = torch.zeros(q, rows, cols, dtype=t.dtype, device=t.device)
+    out[:, :r, :c] = t
+    return out
+
+
+def gemm_tn(A_km, B_kn):
+    """C = A^T B for batches of K-major operands A (q,K,M), B (q,K,N) -> (q,M,N) on the library's tile engine
+    (plmc_gemm_tn): operands are zero-padded to block multiples (a transposed view is made contiguous by the same copy).
+    No autograd: used inside hand-written backward passes (`_var_engine`)."""
+    _hip.require_device(A_km, B_kn)
+    L = _hip.lib()
+    dt, dev = A_km.dtype, A_km.device
+    q, K, M = A_km.shape
+    N = B_kn.shape[-1]
+    nb = L.cdll.plmc_block()
+    Kp, Mp, Np = -(-K // 16) * 16, -(-M // nb) * nb, -(-N // nb) * nb
+    A = _padded(A_km.detach(), Kp, Mp)
+    B = _padded(B_kn.detach().to(dt), Kp, Np)
+    C = torch.empty(q, Mp, Np, dtype=dt, device=dev)
+    L.call("plmc_gemm_tn", dt, 0, Mp, Np, Kp, _hip.ptr(A), Mp, Kp * Mp, _hip.ptr(B), Np, Kp * Np, _hip.ptr(C), Np, Mp * Np, q,
+           _hip.stream_ptr(dev))
+    return C[:, :M, :N]

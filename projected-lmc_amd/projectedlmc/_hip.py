@@ -29,6 +29,7 @@ _TYPED = {
     "plmc_extract_col": [_P, _L, _L, _L, _I, _P, _P, _I, _P],
     "plmc_wt_matvec": [_P, _L, _L, _L, _P, _P, _I, _P],
     "plmc_w_diag": [_P, _L, _L, _L, _P, _I, _P],
+    "plmc_gemm_tn": [_I, _I, _I, _I, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P],
     "plmc_kinv_grad": [_I, _P, _L, _L, _L, _P, _P, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P],
     "plmc_lmc_assemble": [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P],
     "plmc_lmc_cross": [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _P],
@@ -51,6 +52,8 @@ _PLAIN = {
     "plmc_prof_kernels": ([], _I),
     "plmc_prof_name": ([_I], _c.c_char_p),
     "plmc_prof_collect": ([_P, _P, _P, _P], _I),
+    "plmc_prof_mfma_rate": ([_I, _P, _L, _P], _I),
+    "plmc_dev_reload_knobs": ([], _I),
 }
 
 
@@ -75,6 +78,42 @@ def prof_collect():
     L.plmc_prof_collect(ms, la, fl, by)
     return {L.plmc_prof_name(i).decode(): dict(ms=ms[i], launches=la[i], flops=fl[i], bytes=by[i])
             for i in range(k) if la[i] > 0}
+
+
+class knob:
+    """Context manager for a dev knob of the library: set the environment variable, make the library re-read its
+    knobs, restore on exit (tests / bench.py: `with _hip.knob("PLMC_SERIAL", "1"): ...`)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = os.environ.get(self.name)
+        os.environ[self.name] = str(self.value)
+        lib().cdll.plmc_dev_reload_knobs()
+        return self
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = self.old
+        lib().cdll.plmc_dev_reload_knobs()
+        return False
+
+
+def mfma_rate(dtype=torch.float32, device=None):
+    """Measured dense MFMA rate (TFLOP/s) of the device: bare instruction stream, no memory traffic."""
+    L = lib().cdll
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    sink = torch.empty(4 * 1024 * 256, dtype=dtype, device=dev)
+    out = _c.c_double(0.0)
+    with torch.cuda.device(dev):
+        torch.cuda.synchronize(dev)
+        rc = L.plmc_prof_mfma_rate(int(dtype == torch.float64), ptr(sink), sink.numel() * sink.element_size(), _c.byref(out))
+    if rc != 0:
+        raise RuntimeError("plmc_prof_mfma_rate failed: %s" % L.plmc_last_error().decode())
+    return out.value
 
 
 def exported_symbols():

@@ -9,8 +9,8 @@ Backward (what `loss.backward()`, experiments.py:270, derives through gpytorch):
 G = d loss / d A,   Cbar = L^-T G,   Lbar = -tril(Cbar A^T),   Kbar = sym(L^-T Phi(L^T Lbar) L^-1)
 (standard Cholesky adjoint; L^-1 = W comes from the same sweep, `with_inverse`), then the
 kernel-matrix adjoints Kbar, Cbar are pulled back to lengthscales / outputscales / inducing
-locations by the fused HIP kernel `plmc_kernel_vjp`.  The rectangular m x m x n products of the
-adjoint are plain library GEMMs (torch.matmul -> rocBLAS/hipBLASLt).
+locations by the fused HIP kernel `plmc_kernel_vjp`.  The m x m x n products of the adjoint run on the library's own
+tile engine (`plmc_gemm_tn` through `_dense.gemm_tn`; every product is written in "TN" form, C = X^T Y).
 """
 import torch
 
@@ -90,11 +90,13 @@ class WhitenedInterp(torch.autograd.Function):
         osc = osc if ctx.has_os else None
         kind = ctx.kind
         G = G.contiguous()
-        Cbar = W.transpose(-1, -2) @ G                                          # L^-T G          (q,m,n)
-        Lbar = -torch.tril(Cbar @ A.transpose(-1, -2))                          # (q,m,m)
-        P = torch.tril(U @ Lbar)                                                # Phi(L^T Lbar)
+        from ._dense import gemm_tn
+        mT = lambda t: t.transpose(-1, -2)
+        Cbar = gemm_tn(W, G)                                                    # L^-T G = W^T G  (q,m,n)
+        Lbar = -torch.tril(gemm_tn(mT(Cbar), mT(A)))                            # -tril(Cbar A^T) (q,m,m)
+        P = torch.tril(gemm_tn(mT(U), Lbar))                                    # Phi(L^T Lbar),  L^T = U
         P = P - 0.5 * torch.diag_embed(torch.diagonal(P, dim1=-2, dim2=-1))
-        Kbar = W.transpose(-1, -2) @ P @ W
+        Kbar = gemm_tn(W, gemm_tn(mT(P), W))                                    # W^T (P W)
         Kbar = 0.5 * (Kbar + Kbar.transpose(-1, -2))
         # pull the kernel-matrix adjoints back to (Z, ell, oscale); Z enters K_ZZ through both arguments
         gZ1, gE1, gO1 = kernel_vjp(kind, Z, Z, ell, osc, Kbar)
@@ -161,11 +163,12 @@ class GaussianKLToKernelPrior(torch.autograd.Function):
         W, Zs, Z, ell, osc, dg = ctx.saved_tensors
         osc = osc if ctx.has_os else None
         dt = W.dtype
-        Af = W.transpose(-1, -2) @ Zs                                                # Khat^-1 [m, Ls]   (q, n, n+1)
+        from ._dense import gemm_tn
+        Af = gemm_tn(W, Zs)                                                          # Khat^-1 [m, Ls] = W^T Zs (q, n, n+1)
         g_m = Af[..., 0]
         g_Ls = torch.tril(Af[..., 1:]) - torch.diag_embed((1.0 / dg).to(dt))
-        Kinv = W.transpose(-1, -2) @ W
-        Gk = 0.5 * (Kinv - Af @ Af.transpose(-1, -2)) * g.to(dt)[:, None, None]
+        Kinv = gemm_tn(W, W)
+        Gk = 0.5 * (Kinv - gemm_tn(Af.transpose(-1, -2), Af.transpose(-1, -2))) * g.to(dt)[:, None, None]
         gZ, gE, gO = kernel_vjp(ctx.kind, Z, Z, ell, osc, Gk)
         gl = g.to(dt)
         return ((2.0 * gZ).to(dt), gE.to(dt), gO.to(dt) if ctx.has_os else None, gl[:, None] * g_m, gl[:, None, None] * g_Ls,
@@ -218,9 +221,10 @@ def unwhitened_predictive(kind, Z, X, ell, oscale, mvar, Ls, jitter):
     if bool(ws.info.cpu().any()):
         raise RuntimeError("K_ZZ + jitter not positive definite")
     C = ws.A[:, :n, ws.n_pad:ws.n_pad + ns]                                          # U^-T K_ZX
-    B = torch.tril(ws.W[:, :n, :n]).transpose(-1, -2) @ C                            # Khat^-1 K_ZX
+    from ._dense import gemm_tn
+    B = gemm_tn(torch.tril(ws.W[:, :n, :n]), C)                                      # Khat^-1 K_ZX = W^T C
     mean = (B.transpose(-1, -2) @ mvar.to(dt).unsqueeze(-1)).squeeze(-1)
     os_ = torch.ones(q, dtype=dt, device=dev) if osc is None else osc
-    LB = torch.tril(Ls.to(dt)).transpose(-1, -2) @ B
+    LB = gemm_tn(torch.tril(Ls.to(dt)), B)                                            # Ls^T B
     var = os_[:, None] - (C * C).sum(-2) + (LB * LB).sum(-2)
     return mean, var

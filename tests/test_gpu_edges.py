@@ -203,12 +203,10 @@ def test_sweep_is_deterministic_and_schedule_independent(eng, n, q, dtype):
         torch.cuda.synchronize()
         return ws.A.view(it).clone(), ws.logdet.clone(), ws.info.clone()
 
+    from projectedlmc import _hip
     assert "PLMC_SERIAL" not in os.environ
-    os.environ["PLMC_SERIAL"] = "1"
-    try:
+    with _hip.knob("PLMC_SERIAL", "1"):
         ref, ld_ref, info_ref = factor()
-    finally:
-        del os.environ["PLMC_SERIAL"]
     assert not bool(info_ref.any()) and bool(torch.isfinite(ld_ref).all())
     for rep in range(4):
         A, ld, info = factor()

@@ -51,17 +51,26 @@ def test_logprob_and_grad_fp64(eng, kind, n, d, q, use_os):
         assert torch.allclose(os_d.grad.cpu(), w * ref[3], rtol=1e-7, atol=1e-9)
 
 
-@pytest.mark.parametrize("n,d,q,env", [(1300, 3, 2, None), (2100, 4, 8, None), (1300, 3, 2, "PLMC_SERIAL=1"),
-                                       (1300, 3, 2, "PLMC_CUMASK=1"), (1300, 3, 2, "PLMC_WSTREAM=1"),
-                                       (2100, 4, 8, "PLMC_WSTREAM=0"), (1300, 3, 2, "PLMC_GRAD_STREAM=0"),
-                                       (1300, 3, 2, "PLMC_KINV_ORDER=1"), (1300, 3, 2, "PLMC_KINV_ORDER=5")])
+@pytest.mark.parametrize("n,d,q,env", [(1300, 3, 2, None), (2100, 4, 8, None), (3300, 3, 2, None), (1300, 3, 2, "PLMC_SERIAL=1"),
+                                       (2100, 4, 8, "PLMC_GRP=4"), (1300, 3, 2, "PLMC_GRP=3"), (2100, 4, 8, "PLMC_HALF_TILES=0"),
+                                       (1300, 3, 2, "PLMC_HALF_TILES=1"), (1300, 3, 2, "PLMC_GRAD_STREAM=0"),
+                                       (1300, 3, 2, "PLMC_KINV_ORDER=1"), (1300, 3, 2, "PLMC_KINV_ORDER=0"),
+                                       (1300, 3, 2, "PLMC_KINV_ORDER=5")])
 def test_multi_group_sweep_fp64(eng, n, d, q, env, monkeypatch):
-    """Sizes at which the sweep runs its look-ahead schedule (more than two groups of block rows, head / tail
-    updates on separate streams, inverse-factor columns on a third stream for q >= 4, group sizes 4 and 8 +
-    ramp-down), against the dense fp64 oracle; also with the look-ahead, the CU mask, the W stream, the gradient
-    stream and the tile order of the gradient kernel switched (the dev knobs must not change results)."""
-    if env:
-        monkeypatch.setenv(*env.split("="))
+    """Sizes at which the sweep runs its look-ahead schedule (more than two groups of block rows: chain, group panel +
+    head rows and tail on three streams; ragged last group), against the dense fp64 oracle; also with the look-ahead
+    off, other group sizes, half / full tiles for the small launches, the gradient stream and the tile order / general
+    epilogue of the gradient kernel switched (the dev knobs must not change results)."""
+    from projectedlmc import _hip
+    if env and env.startswith("PLMC_GRAD_STREAM"):
+        monkeypatch.setenv(*env.split("="))                     # Python-level knob, read per call
+    elif env:
+        with _hip.knob(*env.split("=")):
+            return _multi_group_body(eng, n, d, q)
+    return _multi_group_body(eng, n, d, q)
+
+
+def _multi_group_body(eng, n, d, q):
     X, y, ell, noise, osc = _problem(n, d, q, seed=n)
     ref = gm.exact_latent_log_prob_analytic("matern", X, ell, noise, y, osc, 2.5)
     dev = torch.device("cuda:0")

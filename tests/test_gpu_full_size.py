@@ -86,7 +86,6 @@ def test_config2_full_size_fp64(plmc):
     lp_h = _lmc_engine.lmc_exact_log_prob("rbf", f(X), f(ell), None, f(B), f(Sigma), 0.5 * f(Y.reshape(-1)))
     assert abs(float(lp_h) - float(lp) - 0.375 * quad) < 1e-9 * abs(float(lp))
     # (1) dense oracle value (host: ~1.5e12 flop)
-    torch.set_num_threads(max(1, torch.get_num_threads()))
     ref = float(ld.lmc_exact_mll("rbf", X, Y, ell, B, Sigma)) * N
     assert abs(float(lp) - ref) < 1e-9 * abs(ref), (float(lp), ref)
 

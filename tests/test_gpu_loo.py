@@ -15,7 +15,7 @@ DEV = "cuda:0"
 
 def _loo_ref(kind, nu, X, ell, noise, y):
     K = gm.kernel_matrix(kind, X, X, ell, None, nu) + noise.reshape(-1, 1, 1) * torch.eye(X.shape[0], dtype=X.dtype)
-    Kinv = torch.linalg.inv(K)
+    Kinv = torch.cholesky_inverse(torch.linalg.cholesky(K))      # SPD: no LU (batched MKL getri is flaky after big factorisations)
     s2 = 1.0 / torch.diagonal(Kinv, dim1=-2, dim2=-1)
     return s2, (Kinv @ y.unsqueeze(-1)).squeeze(-1) * s2
 

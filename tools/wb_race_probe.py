@@ -64,10 +64,9 @@ def main():
     ell = torch.linspace(0.4, 1.0, a.q, dtype=dt)[:, None].expand(a.q, a.d).contiguous().to(dev)
     noise = torch.linspace(0.05, 0.5, a.q, dtype=dt).to(dev)
     ws = _engine.Workspace(a.n, a.q, 1, dt, dev, True)
-    os.environ["PLMC_SERIAL"] = "1"
-    ref, ld_ref, info_ref = factor(ws, X, ell, noise, y)
-    ref2, _, _ = factor(ws, X, ell, noise, y)
-    del os.environ["PLMC_SERIAL"]
+    with _hip.knob("PLMC_SERIAL", "1"):
+        ref, ld_ref, info_ref = factor(ws, X, ell, noise, y)
+        ref2, _, _ = factor(ws, X, ell, noise, y)
     res = {"lib": os.environ.get("PLMC_LIB", _hip.LIB_PATH), "tag": a.tag, "n": a.n, "q": a.q, "dtype": a.dtype,
            "serial_repeatable": bool(torch.equal(ref.view(torch.uint8), ref2.view(torch.uint8))),
            "serial_tiles_differ": len(tiles_differ(ref2, ref, ws)),
