@@ -49,6 +49,7 @@ struct Knobs {
   double half_tiles;   // PLMC_HALF_TILES: 0 never, 1 always, N > 1 = tile-count threshold (default 640)
   int grp;             // PLMC_GRP: fixed group size of the sweep (default 0 = 8)
   bool serial;         // PLMC_SERIAL: one stream, no look-ahead
+  int bulk_lds;        // PLMC_BULK_LDS: extra dynamic LDS bytes per bulk workgroup (caps bulk occupancy); -1 = default by q
   int kinv_order;      // PLMC_KINV_ORDER: tile order of the gradient kernel (0 XCD-dealt, 1 grid, 4 longest first, 5 = 4 + general epilogue)
 };
 const Knobs &knobs();

@@ -184,6 +184,87 @@ __device__ __forceinline__ void tile_mainloop(Acc<T, MT, NT> &acc, const T *__re
   }
 }
 
+// Burst form of the main loop for the LATENCY-BOUND chain kernels of the sweep (row panel, rank-128 updates inside a
+// group's triangle: K = 128, a handful of tiles per launch, running beside MFMA-saturating bulk kernels).  The
+// double-buffered loop above keeps ONE slab in flight, so a K = 128 tile is 8 dependent global round trips -- ~1 us each
+// on an idle GPU, 5-10 us when the bulk kernels fill the memory system: that, not the arithmetic, is what made a
+// 10 us panel take 50-100 us in situ.  Here all loads of BURST slabs are issued before the first is used (register
+// staged: BURST x (NCHA + NCH) x 16 bytes per thread; fp32 half tiles: 96 registers for the whole K = 128), so a tile
+// costs K / (16 BURST) round trips.  Same LDS layout, same accumulation order as tile_mainloop (bit-identical results).
+// K % (BK * BURST) == 0.  All 256 threads must call it; ends with a barrier.
+template <typename T, int MT, int NT, int BURST>
+__device__ __forceinline__ void tile_mainloop_burst(Acc<T, MT, NT> &acc, const T *__restrict__ Ag, int64_t lda,
+                                                    const T *__restrict__ Bg, int64_t ldb, int K, T *smem) {
+  using Tr = Traits<T>;
+  using vec_t = typename Tr::vec_t;
+  constexpr int EPV = Tr::EPV;
+  constexpr int AW = 32 * MT, BW = 32 * NT;
+  constexpr int CPR = BW / EPV, CPRA = AW / EPV;
+  constexpr int NCH = BK * CPR / NTHREADS, NCHA = BK * CPRA / NTHREADS;
+  constexpr int RSTEP = NTHREADS / CPR, RSTEPA = NTHREADS / CPRA;
+  static_assert(NCHA >= 1 && NCH >= 1 && RSTEP % 4 == 0 && RSTEPA % 4 == 0, "slab split");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  T *sA = smem;
+  T *sB = smem + SB_OFF;
+  const int row0 = tid / CPR, col0 = (tid % CPR) * EPV;
+  const int row0a = tid / CPRA, col0a = (tid % CPRA) * EPV;
+  const char *baseA = reinterpret_cast<const char *>(Ag);
+  const char *baseB = reinterpret_cast<const char *>(Bg);
+  const int64_t stepA = (int64_t)BK * lda * (int64_t)sizeof(T), stepB = (int64_t)BK * ldb * (int64_t)sizeof(T);
+  unsigned offA[NCHA], offB[NCH];
+#pragma unroll
+  for (int h = 0; h < NCHA; ++h) offA[h] = (unsigned)(((int64_t)(row0a + h * RSTEPA) * lda + col0a) * (int64_t)sizeof(T));
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) offB[h] = (unsigned)(((int64_t)(row0 + h * RSTEP) * ldb + col0) * (int64_t)sizeof(T));
+  const int rp0 = (row0 & 3) * 4 + (row0 >> 2), rp0a = (row0a & 3) * 4 + (row0a >> 2);
+  T *swB = sB + rp0 * LDT + col0, *swA = sA + rp0a * LDT + col0a;
+  const int fk = lane >> 4, fm = lane & 15;
+  const T *pa0 = sA + fk * 4 * LDT + wm * (16 * MT) + fm, *pb0 = sB + fk * 4 * LDT + wn * (16 * NT) + fm;
+  const int nburst = K / (BK * BURST);
+#pragma unroll 1
+  for (int bt = 0; bt < nburst; ++bt) {
+    vec_t ra[BURST][NCHA], rb[BURST][NCH];
+#pragma unroll
+    for (int s = 0; s < BURST; ++s) {                  // every load of the burst in flight before the first use
+      const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(baseA), 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(baseB), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int h = 0; h < NCHA; ++h) ra[s][h] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rA, offA[h], 0, 0));
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) rb[s][h] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(rB, offB[h], 0, 0));
+      baseA += stepA;
+      baseB += stepB;
+    }
+#pragma unroll
+    for (int s = 0; s < BURST; ++s) {
+      const int buf = s & 1;
+      T *wa = swA + buf * (BK * LDT), *wb = swB + buf * (BK * LDT);
+#pragma unroll
+      for (int h = 0; h < NCHA; ++h) *reinterpret_cast<vec_t *>(wa + h * (RSTEPA / 4) * LDT) = ra[s][h];
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) *reinterpret_cast<vec_t *>(wb + h * (RSTEP / 4) * LDT) = rb[s][h];
+      __syncthreads();                                 // slab s visible; every wave is past the reads of slab s - 1
+      const T *pa = pa0 + buf * (BK * LDT), *pb = pb0 + buf * (BK * LDT);
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        T a[MT], b[NT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[t] = pa[ks * LDT + t * 16];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = pb[ks * LDT + t * 16];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc.v[mt][nt] = Tr::mfma(a[mt], b[nt], acc.v[mt][nt]);
+      }
+    }
+    __syncthreads();                                   // both stages free (next burst / the caller's epilogue)
+  }
+}
+
 // Coalesced epilogue: C[tile] (+)= acc through LDS.  The MFMA accumulator layout gives each lane 4-byte
 // pieces of 64-byte row segments (64 scalar loads + 64 scalar stores per lane for a read-modify-write);
 // transposing the tile through LDS in two 64-row halves turns that into 16-byte accesses of full

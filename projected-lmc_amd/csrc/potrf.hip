@@ -30,6 +30,8 @@
 namespace plmc {
 
 constexpr int GMAX = 8;                       // largest group (block rows)
+// slabs of 16 rows the chain kernels keep in flight (tile_mainloop_burst): fp32 all 8 of K = 128, fp64 4 (registers)
+template <typename T> constexpr int CHAIN_BURST = sizeof(T) == 8 ? 4 : 8;
 constexpr int LDG = (GMAX + 1) * NB;          // leading dimension of the group scratch matrices (Wg, Vg, Ph): an odd number of
                                               // 128-blocks, like lda -- a power-of-two row stride camps on a few L2 channels
 // per-latent scratch behind the m inverse diagonal blocks of Vd: Wg + two Vg (ping-pong), GMAX^2 blocks each
@@ -51,7 +53,7 @@ template <typename T> struct ColMap {
 // Row panel solve P <- V_rr^T P for block row r.  grid (nU + Taug + nW, q, 4 / NT): NT = 2 splits every 128 x 128 tile
 // into two 64-COLUMN halves -- the solve is in place and every output row needs all 128 input rows of its column,
 // so only a column split keeps workgroups independent -- for launches that would not fill the CUs.
-template <typename T, int NT>
+template <typename T, int NT, bool BURSTED = false>
 __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_panel(T *A, int64_t lda, int64_t strideA, int r, ColMap<T> cm,
                                                      const T *__restrict__ Vd, int64_t strideV) {
   __builtin_amdgcn_s_setprio(3);       // chain kernel: ahead of the concurrently running trailing update
@@ -69,7 +71,11 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_panel(T *A, int
   const T *V = Vd + (int64_t)lat * strideV + (int64_t)r * NB * NB;
   Acc<T, 4, NT> acc;
   acc.zero();
-  tile_mainloop<T, false, false, 4, NT>(acc, V, NB, P, ldp, NB, smem);
+  // BURSTED (few latents: the chain is the critical path and its launches find free slots at once): all of K = 128
+  // (fp64: half of it) in flight at once.  With many latents the launches queue for CU slots behind bulk tiles and the
+  // extra staging registers only make a workgroup harder to place (q = 8: 48 -> 55 us in situ), so the plain loop stays.
+  if constexpr (BURSTED) tile_mainloop_burst<T, 4, NT, CHAIN_BURST<T>>(acc, V, NB, P, ldp, NB, smem);
+  else tile_mainloop<T, false, false, 4, NT>(acc, V, NB, P, ldp, NB, smem);
   tile_store<T, 4, NT>(acc, P, ldp);
 }
 
@@ -80,17 +86,18 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_panel(T *A, int
 //   aug       : read-modify-write.
 //   W column cb < r_lo : read-modify-write, full panel depth;
 //            cb >= r_lo : first touch -> plain store; only the panel rows cb..r_hi contribute (W[r][cb] = 0 for r < cb).
-// ROLE 0 = the big trailing ("tail") update, 1 = the single-row launches inside a group's triangle (latency-critical:
-// raised wave priority), 2 = the look-ahead updates of the next group's triangle.  Separate symbols keep the launch
-// shapes apart in kernel traces and counter passes.
+// ROLE 0 = the big trailing ("tail") update, 1 = the rank-128 launches inside a group's triangle (latency-critical:
+// raised wave priority), 2 = the look-ahead update of the next group's triangle (few tiles, critical path: burst
+// loads), 3 = the "head" rows of the next group on the second helper stream (bulk-sized), 4 = role 1 with burst loads
+// (few latents).  Separate symbols keep the launch shapes apart in kernel traces and counter passes.
 // MT = 2 splits every 128 x 128 tile into two 64-row halves (grid.y doubled): twice the workgroups for the chain's
 // launches when full tiles would not fill the CUs.  (k_panel cannot be split this way: it works in place and every
 // output row needs all 128 input rows of its column.)
 template <typename T, int ROLE, int MT = 4>
 __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, int64_t lda, int64_t strideA, int ib0, int r_lo, int r_hi,
                                                       ColMap<T> cm, int skip_ib, int skip_jb) {
-  if (ROLE == 1) __builtin_amdgcn_s_setprio(3);
-  if (ROLE == 2) __builtin_amdgcn_s_setprio(2);       // look-ahead rows: the next chain waits for them
+  if (ROLE == 1 || ROLE == 4) __builtin_amdgcn_s_setprio(3);
+  if (ROLE == 2 || ROLE == 3) __builtin_amdgcn_s_setprio(2);       // look-ahead rows: the next chain waits for them
   // plain row-major tile order: an XCD-dealt super-block order (xcd_tri_decode, gemm_core.hpp) was 3 % faster for a
   // launch that has the GPU to itself and 25 % slower in the sweep, where launches from several streams
   // interleave and "workgroup w lands on XCD w % 8" no longer holds
@@ -120,8 +127,15 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
   __shared__ __align__(16) T smem[tile_smem_elems<T>()];
   Acc<T, MT> acc;
   acc.zero();
-  tile_mainloop<T, false, false, MT>(acc, Al + (int64_t)kr0 * lda + (int64_t)ib * NB + h0, lda, Cb + (int64_t)kr0 * ldc + col0, ldc,
-                                     depth, smem);
+  const T *Ap = Al + (int64_t)kr0 * lda + (int64_t)ib * NB + h0, *Bp = Cb + (int64_t)kr0 * ldc + col0;
+  // the rank-128 updates inside a group's triangle (ROLE 1, half tiles) are latency-bound: burst loads (gemm_core.hpp)
+  if constexpr (ROLE == 4) {                           // rank-128 update of the triangle, few latents (see k_panel)
+    tile_mainloop_burst<T, MT, 4, CHAIN_BURST<T>>(acc, Ap, lda, Bp, ldc, depth, smem);
+  } else if constexpr (ROLE == 2 && MT == 2) {         // look-ahead update of the next triangle: few tiles, critical path
+    tile_mainloop_burst<T, MT, 4, 4>(acc, Ap, lda, Bp, ldc, depth, smem);
+  } else {
+    tile_mainloop<T, false, false, MT>(acc, Ap, lda, Bp, ldc, depth, smem);
+  }
   T *C = Cb + ((int64_t)ib * NB + h0) * ldc + col0;
   if (first) tile_writeback<T, WB_STORE_NEG, MT>(acc, C, ldc, smem);   // C = -P^T P (first touch of a W tile)
   else tile_writeback<T, WB_SUB, MT>(acc, C, ldc, smem);               // C -= P^T P
@@ -134,10 +148,11 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
 // of row i would overwrite what the workgroups of rows > i still read -- and copied back by k_gpanel_copy.  (A strip
 // form, one workgroup walking i = G-1 .. 0 in place, needs no buffer but has G times fewer workgroups: 61 TF at q = 8,
 // 15 TF at q = 1 on the benchmark shape.)  Heavy rows first.  grid (tiles, G, q).
-template <typename T>
-__global__ __launch_bounds__(NTHREADS, (sizeof(T) == 8 ? 2 : 4)) void k_gpanel_rows(const T *A, int64_t lda, int64_t strideA, int g0, int G,
-                                                           ColMap<T> cm, const T *__restrict__ Vg, int64_t ldv, int64_t strideVg,
-                                                           T *__restrict__ Pb, int64_t ldp, int64_t strideP, int head) {
+template <typename T, int HEAD>
+__global__ __launch_bounds__(NTHREADS, (sizeof(T) == 8 || HEAD ? 2 : 4)) void k_gpanel_rows(const T *A, int64_t lda, int64_t strideA, int g0,
+                                                           int G, ColMap<T> cm, const T *__restrict__ Vg, int64_t ldv,
+                                                           int64_t strideVg, T *__restrict__ Pb, int64_t ldp, int64_t strideP) {
+  constexpr int head = HEAD;
   if (head) __builtin_amdgcn_s_setprio(2);
   __shared__ __align__(16) T smem[tile_smem_elems<T>()];
   const int lat = blockIdx.z, t = blockIdx.x;
@@ -160,7 +175,10 @@ __global__ __launch_bounds__(NTHREADS, (sizeof(T) == 8 ? 2 : 4)) void k_gpanel_r
     if (i < 0) break;
     Acc<T> acc;
     acc.zero();
-    tile_mainloop<T, false, false>(acc, Vg + (int64_t)lat * strideVg + (int64_t)i * NB, ldv, S, lds, (i + 1) * NB, smem);
+    if constexpr (HEAD)                                // latency-critical: four slabs in flight (tile_mainloop_burst)
+      tile_mainloop_burst<T, 4, 4, (sizeof(T) == 8 ? 2 : 4)>(acc, Vg + (int64_t)lat * strideVg + (int64_t)i * NB, ldv, S, lds, (i + 1) * NB, smem);
+    else
+      tile_mainloop<T, false, false>(acc, Vg + (int64_t)lat * strideVg + (int64_t)i * NB, ldv, S, lds, (i + 1) * NB, smem);
     tile_writeback<T, WB_STORE>(acc, Pb + (int64_t)lat * strideP + (int64_t)i * NB * ldp + (int64_t)t * NB, ldp, smem);
     __syncthreads();                   // staging buffer free before the second product refills it
   }
@@ -350,6 +368,10 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const Knobs &kn = knobs();                            // dev knobs: read once per process (api.hip)
   const double hthr = kn.half_tiles;
   const bool serial = kn.serial;
+  // With one or two latents the chain is the critical path: the bulk kernels then ask for 16 KB of LDS they do not use,
+  // which caps them at three workgroups per CU and leaves a slot per CU to the chain's small launches (q = 2: 11.4 ->
+  // 11.0 ms/step, q = 1: 7.8 -> 7.5; with many latents the bulk is the bound and the cap costs 1-2 %).
+  const unsigned bulk_lds = (unsigned)(kn.bulk_lds >= 0 ? kn.bulk_lds : (q <= 2 ? 16000 : 0));
 
   auto diag = [&](int r, int g0, hipStream_t s) {
     ProfScope ps(PK_DIAG, s, q * (2.0 / 3.0) * nb3, q * 3.0 * nb * nb * esz);
@@ -369,15 +391,18 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     if (nt == 0) return;
     // algorithmic: triangular solve of nt*NB columns with a 128 x 128 factor = nb^2 flops per column
     ProfScope ps(PK_PANEL, s, q * (double)nt * nb3, q * 2.0 * nt * nb * nb * esz);
-    if ((double)nt * q <= hthr)
+    if ((double)nt * q <= hthr && q <= 2)
+      hipLaunchKernelGGL((k_panel<T, 2, true>), dim3(nt, q, 2), dim3(NTHREADS), 0, s, A, lda, strideA, r, cm, Vd, strideV);
+    else if ((double)nt * q <= hthr)
       hipLaunchKernelGGL((k_panel<T, 2>), dim3(nt, q, 2), dim3(NTHREADS), 0, s, A, lda, strideA, r, cm, Vd, strideV);
     else
       hipLaunchKernelGGL((k_panel<T, 4>), dim3(nt, q, 1), dim3(NTHREADS), 0, s, A, lda, strideA, r, cm, Vd, strideV);
   };
-  // cls: profiler class of the launch -- PK_TRAIL (the big trailing update), PK_TRAIL_HEAD (look-ahead updates of
-  // the next group's tiles on the chain stream), PK_TRAIL_ROW (single row inside a group's triangle)
+  // cls: profiler class of the launch -- PK_TRAIL (the big trailing update), PK_TRAIL_HEAD (look-ahead updates of the next
+  // group's rows: `crit` = the triangle on the chain stream, else the other columns on the second helper stream),
+  // PK_TRAIL_ROW (rank-128 update inside a group's triangle)
   auto update = [&](int ib0, int nrows, int r_lo, int r_hi, const ColMap<T> &cm, hipStream_t s, int cls, int skip_ib = 0,
-                    int skip_jb = 0) {
+                    int skip_jb = 0, bool crit = false) {
     const int Cn = cm.nU + cm.Taug + cm.nW;
     if (nrows <= 0 || Cn == 0) return;
     const double depth = (r_hi - r_lo + 1) * nb, nr = (double)nrows;
@@ -403,10 +428,12 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     // launches with few tiles run on 64-row half tiles: twice the workgroups
     const bool half = cls != PK_TRAIL && (double)Cn * nrows * q <= hthr;
     const dim3 grid(Cn, half ? 2 * nrows : nrows, q);
+    const unsigned dyn = (cls == PK_TRAIL || (cls == PK_TRAIL_HEAD && !crit)) ? bulk_lds : 0u;
 #define PLMC_UPD(ROLE, MT) \
-  hipLaunchKernelGGL((k_update<T, ROLE, MT>), grid, dim3(NTHREADS), 0, s, A, lda, strideA, ib0, r_lo, r_hi, cm, skip_ib, skip_jb)
-    if (cls == PK_TRAIL_ROW) { if (half) PLMC_UPD(1, 2); else PLMC_UPD(1, 4); }
-    else if (cls == PK_TRAIL_HEAD) { if (half) PLMC_UPD(2, 2); else PLMC_UPD(2, 4); }
+  hipLaunchKernelGGL((k_update<T, ROLE, MT>), grid, dim3(NTHREADS), dyn, s, A, lda, strideA, ib0, r_lo, r_hi, cm, skip_ib, skip_jb)
+    if (cls == PK_TRAIL_ROW) { if (half && q <= 2 && r_hi == r_lo) PLMC_UPD(4, 2); else if (half) PLMC_UPD(1, 2); else PLMC_UPD(1, 4); }
+    else if (cls == PK_TRAIL_HEAD && crit) { if (half) PLMC_UPD(2, 2); else PLMC_UPD(2, 4); }
+    else if (cls == PK_TRAIL_HEAD) { if (half) PLMC_UPD(3, 2); else PLMC_UPD(3, 4); }
     else PLMC_UPD(0, 4);
 #undef PLMC_UPD
   };
@@ -419,8 +446,12 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     const int64_t ldp = head ? (int64_t)LDG : lda;
     {
       ProfScope ps(PK_GPANEL, s, q * (double)nt * prods * 2.0 * nb3, q * (double)nt * (prods + G) * nb * nb * esz);
-      hipLaunchKernelGGL((k_gpanel_rows<T>), dim3(nt, head ? G : (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)A, lda, strideA, g0, G, cm,
-                         Vg, (int64_t)LDG, strideV, Pb, ldp, strideV, head);
+      if (head)
+        hipLaunchKernelGGL((k_gpanel_rows<T, 1>), dim3(nt, G, q), dim3(NTHREADS), 0, s, (const T *)A, lda, strideA, g0, G, cm, Vg, (int64_t)LDG,
+                           strideV, Pb, ldp, strideV);
+      else
+        hipLaunchKernelGGL((k_gpanel_rows<T, 0>), dim3(nt, (G + 1) / 2, q), dim3(NTHREADS), bulk_lds, s, (const T *)A, lda, strideA, g0, G, cm, Vg,
+                           (int64_t)LDG, strideV, Pb, ldp, strideV);
     }
     hipLaunchKernelGGL((k_gpanel_copy<T>), dim3(nt, G, q), dim3(NTHREADS), 0, s, A, lda, strideA, g0, cm, (const T *)Pb, ldp, strideV);
   };
@@ -513,7 +544,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     gpanel(g0, G, cm_buf(g1, g2 - g1, 0, 0, 0), Vg, C, 1);                      // head columns R1
     (void)hipEventRecord(e_gh, C);
     if (gi > 0) (void)hipStreamWaitEvent(C, e_tail, 0);                        // tail(gi - 1): rows R1 up to date
-    update(g1, g2 - g1, g0, g1 - 1, cm_buf(g1, g2 - g1, 0, 0, 0), C, PK_TRAIL_HEAD);   // U1: next triangle
+    update(g1, g2 - g1, g0, g1 - 1, cm_buf(g1, g2 - g1, 0, 0, 0), C, PK_TRAIL_HEAD, 0, 0, true);   // U1: next triangle
 
     (void)hipStreamWaitEvent(H, e_v, 0);
     gpanel(g0, G, cm_buf(g2, m - g2, Taug, 0, g0), Vg, H, 0);                   // rest of the panel columns
