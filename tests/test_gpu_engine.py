@@ -165,3 +165,20 @@ def test_assembled_covariance_entries_fp32(eng, kind, d):
         got = ws.A[i, :n, :n].double().cpu()
         err = (got - Kref).triu().abs().max()
         assert float(err) < 6e-7 * (1.0 + float(nc[i])), (kind, d, float(err))
+
+
+def test_non_current_device(eng):
+    """The library keys its helper streams / events on the CURRENT device: a model that lives on another device than the
+    current one must still work.  Needs two GPUs; the 1-GPU test boxes skip it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    assert torch.cuda.current_device() == 0
+    dev = torch.device("cuda:1")
+    X, y, ell, noise, osc = _problem(700, 3, 2, seed=3)
+    ref = gm.exact_latent_log_prob_analytic("matern", X, ell, noise, y, osc, 2.5)
+    ell_d = ell.to(dev).requires_grad_()
+    lp = eng.exact_latent_log_prob("matern52", X.to(dev), ell_d, osc.to(dev), noise.to(dev), y.to(dev))
+    lp.sum().backward()
+    assert torch.cuda.current_device() == 0
+    assert torch.allclose(lp.detach().cpu(), ref[0], rtol=1e-10)
+    assert torch.allclose(ell_d.grad.cpu(), ref[1], rtol=1e-7, atol=1e-9)
