@@ -29,7 +29,9 @@
  *     rows, its transposed copies and the panel buffers of the group's block rows).
  *   - "W, ldw, strideW" arguments below: pointer to the first W column of latent 0 inside the factor
  *     buffer (A + n_pad + naug_pad), ldw = lda, strideW = strideA -- or any buffer of that layout.
- *   - kernel kinds: PLMC_RBF, PLMC_MATERN12, PLMC_MATERN32, PLMC_MATERN52.
+ *   - kernel kinds: PLMC_RBF, PLMC_MATERN12, PLMC_MATERN32, PLMC_MATERN52 (stationary ARD kernels on x / ell) and
+ *     PLMC_SPLINE (the reference's SplineKernel, projected_lmc.py:26-36: no lengthscale -- pass ell = 1; accepted by
+ *     plmc_assemble_*, plmc_assemble_cross_* and plmc_kinv_grad_* only).
  */
 #ifndef PLMC_H
 #define PLMC_H
@@ -41,7 +43,7 @@
 extern "C" {
 #endif
 
-enum { PLMC_RBF = 0, PLMC_MATERN12 = 1, PLMC_MATERN32 = 2, PLMC_MATERN52 = 3 };
+enum { PLMC_RBF = 0, PLMC_MATERN12 = 1, PLMC_MATERN32 = 2, PLMC_MATERN52 = 3, PLMC_SPLINE = 4 };
 
 /* Library identification / geometry. */
 int         plmc_version(void);

@@ -35,9 +35,16 @@ def inv_softplus(y):
 def kernel_matrix(kind, X1, X2, ell, outputscale=None, nu=2.5):
     """Batched ARD covariance.  X1: (n1,d), X2: (n2,d), ell: (q,d) -> (q,n1,n2).
 
-    kind in {"rbf", "matern"}.  Uses direct differences (x-x')/l, which equals
-    gpytorch's mean-centred |a|^2+|b|^2-2ab form in exact arithmetic.
+    kind in {"rbf", "matern", "spline"}.  Uses direct differences (x-x')/l, which equals
+    gpytorch's mean-centred |a|^2+|b|^2-2ab form in exact arithmetic.  "spline" restates the reference's own
+    SplineKernel.forward (projected_lmc.py:26-36; `ell` only gives the batch size).
     """
+    if kind == "spline":
+        mins = torch.min(X1.unsqueeze(-2), X2.unsqueeze(-3))
+        maxes = torch.max(X1.unsqueeze(-2), X2.unsqueeze(-3))
+        K = (1 + mins * maxes + 0.5 * mins ** 2 * (maxes - mins / 3)).prod(dim=-1)
+        K = K.unsqueeze(0).expand(ell.shape[0], -1, -1)
+        return K if outputscale is None else K * outputscale.reshape(-1, 1, 1)
     ell = ell.reshape(ell.shape[0], 1, -1)                      # (q,1,d)
     a = X1.unsqueeze(0) / ell                                   # (q,n1,d)
     b = X2.unsqueeze(0) / ell

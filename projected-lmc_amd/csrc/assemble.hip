@@ -48,14 +48,15 @@ __global__ __launch_bounds__(NTHREADS) void k_assemble(int kind, const T *__rest
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int gj = jb * NB + c0 + c;
-        T r2 = T(0);
+        T r2 = T(0), sp = T(1);
         for (int k = 0; k < d; ++k) {
           T df = ui[r * ldu + k] - uj[(c0 + c) * ldu + k];
           r2 += df * df;
+          if (kind == K_SPLINE) sp *= spline_factor(ui[r * ldu + k], uj[(c0 + c) * ldu + k]);
         }
         T val;
         if (gi < n && gj < n) {
-          val = os * kern_value<T>(kind, r2);
+          val = os * (kind == K_SPLINE ? sp : kern_value<T>(kind, r2));
           if (gi == gj) val += nz;
         } else {
           val = (gi == gj) ? T(1) : T(0);       // identity padding keeps the padded factor trivial
@@ -192,12 +193,13 @@ __global__ __launch_bounds__(NTHREADS) void k_assemble_cross(int kind, const T *
   const T *el = ell + (int64_t)lat * d;
   T val = T(0);
   if (i < n) {
-    T r2 = T(0);
+    T r2 = T(0), sp = T(1);
     for (int k = 0; k < d; ++k) {
       T df = (X[i * d + k] - Xs[(int64_t)j * d + k]) / el[k];
       r2 += df * df;
+      if (kind == K_SPLINE) sp *= spline_factor(X[i * d + k] / el[k], Xs[(int64_t)j * d + k] / el[k]);
     }
-    val = (oscale ? oscale[lat] : T(1)) * kern_value<T>(kind, r2);
+    val = (oscale ? oscale[lat] : T(1)) * (kind == K_SPLINE ? sp : kern_value<T>(kind, r2));
   }
   A[(int64_t)lat * strideA + i * lda + col0 + j] = val;
 }
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(NTHREADS) void k_assemble_cross(int kind, const T *
 template <typename T>
 int assemble_impl(int kind, const T *X, int n, int d, const T *ell, const T *oscale, const T *noise, T *A,
                   int64_t lda, int64_t strideA, int q, void *stream) {
-  PLMC_REQUIRE(kind >= 0 && kind <= 3, "unknown kernel kind");
+  PLMC_REQUIRE(kind >= 0 && kind <= 4, "unknown kernel kind");
   PLMC_REQUIRE(X && ell && noise && A, "null pointer");
   PLMC_REQUIRE(n > 0 && q > 0 && d > 0 && d <= MAX_DIM, "need n>0, q>0, 0<d<=plmc_max_dim()");
   const int64_t n_pad = plmc_pad(n);
@@ -214,10 +216,10 @@ int assemble_impl(int kind, const T *X, int n, int d, const T *ell, const T *osc
   const int m = (int)(n_pad / NB);
   size_t smem = 2 * NB * (d + 1) * sizeof(T);
   ProfScope ps(PK_ASSEMBLE, (hipStream_t)stream, 0.0, q * ((double)n_pad * n_pad / 2) * sizeof(T));
-  if (d <= 4)
+  if (d <= 4 && kind != K_SPLINE)              // the spline kernel is evaluated by the general kernel (not a function of r2)
     hipLaunchKernelGGL((k_assemble_small<T, 4>), dim3(m, m, q), dim3(NTHREADS), 0, (hipStream_t)stream, kind, X, n, d,
                        ell, oscale, noise, A, lda, strideA);
-  else if (d <= 8)
+  else if (d <= 8 && kind != K_SPLINE)
     hipLaunchKernelGGL((k_assemble_small<T, 8>), dim3(m, m, q), dim3(NTHREADS), 0, (hipStream_t)stream, kind, X, n, d,
                        ell, oscale, noise, A, lda, strideA);
   else
@@ -246,7 +248,7 @@ int write_rhs_impl(const T *rhs, int nrhs, int n, T *A, int64_t lda, int64_t str
 template <typename T>
 int assemble_cross_impl(int kind, const T *X, int n, const T *Xs, int ns, int d, const T *ell, const T *oscale, T *Out,
                         int64_t ldo, int64_t strideO, int64_t col0, int64_t n_rows, int q, void *stream) {
-  PLMC_REQUIRE(kind >= 0 && kind <= 3, "unknown kernel kind");
+  PLMC_REQUIRE(kind >= 0 && kind <= 4, "unknown kernel kind");
   PLMC_REQUIRE(X && Xs && ell && Out, "null pointer");
   PLMC_REQUIRE(n > 0 && ns > 0 && q > 0 && d > 0 && d <= MAX_DIM, "bad sizes");
   PLMC_REQUIRE(n_rows >= n && col0 >= 0 && col0 + ns <= ldo, "cross block exceeds the output buffer");

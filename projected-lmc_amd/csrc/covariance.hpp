@@ -6,7 +6,15 @@
 
 namespace plmc {
 
-enum { K_RBF = 0, K_MATERN12 = 1, K_MATERN32 = 2, K_MATERN52 = 3 };
+enum { K_RBF = 0, K_MATERN12 = 1, K_MATERN32 = 2, K_MATERN52 = 3, K_SPLINE = 4 };
+
+// One factor of the reference's SplineKernel (projected_lmc.py:26-36): k(x, x') = prod_k [1 + m M + m^2 (M - m / 3) / 2],
+// m = min(x_k, x'_k), M = max(x_k, x'_k).  Not a function of the distance and without a lengthscale: the kernels that
+// take a `kind` evaluate it from the staged inputs themselves (callers pass ell = 1) instead of through r2.
+template <typename T> __device__ __forceinline__ T spline_factor(T a, T b) {
+  const T mn = a < b ? a : b, mx = a < b ? b : a;
+  return T(1) + mn * mx + T(0.5) * mn * mn * (mx - mn * T(1.0 / 3.0));
+}
 
 __device__ __forceinline__ float  dexp(float x) { return expf(x); }
 __device__ __forceinline__ double dexp(double x) { return exp(x); }

@@ -82,7 +82,17 @@ __device__ __forceinline__ void grad_tile_small(const Acc<T> &acc, T *smem, T os
           r2p += df[j] * df[j];
         }
         T val, base;
-        kern_value_base_fast(KIND, r2p.x + r2p.y, val, base);
+        if constexpr (KIND == K_SPLINE) {                // no lengthscale: the value only feeds the outputscale sum
+          val = T(1);
+#pragma unroll
+          for (int j = 0; j < NP; ++j) {
+            const T2 xr = *reinterpret_cast<const T2 *>(uir + 2 * j);
+            val *= spline_factor(xr.x, u2[j].x) * spline_factor(xr.y, u2[j].y);
+          }
+          base = T(0);
+        } else {
+          kern_value_base_fast(KIND, r2p.x + r2p.y, val, base);
+        }
         T w = smem[L::AI + row] * a_j - kin;
         if (!INTERIOR) {
           const int gi = ib * NB + row;
@@ -175,12 +185,14 @@ __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad
       if (kind == K_RBF) PLMC_GRAD_TILE(K_RBF, true);
       else if (kind == K_MATERN12) PLMC_GRAD_TILE(K_MATERN12, true);
       else if (kind == K_MATERN32) PLMC_GRAD_TILE(K_MATERN32, true);
-      else PLMC_GRAD_TILE(K_MATERN52, true);
+      else if (kind == K_MATERN52) PLMC_GRAD_TILE(K_MATERN52, true);
+      else PLMC_GRAD_TILE(K_SPLINE, false);            // rare kernel: one (predicated) instantiation serves all tiles
     } else {
       if (kind == K_RBF) PLMC_GRAD_TILE(K_RBF, false);
       else if (kind == K_MATERN12) PLMC_GRAD_TILE(K_MATERN12, false);
       else if (kind == K_MATERN32) PLMC_GRAD_TILE(K_MATERN32, false);
-      else PLMC_GRAD_TILE(K_MATERN52, false);
+      else if (kind == K_MATERN52) PLMC_GRAD_TILE(K_MATERN52, false);
+      else PLMC_GRAD_TILE(K_SPLINE, false);
     }
 #undef PLMC_GRAD_TILE
   } else {
@@ -232,7 +244,14 @@ __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad
             r2 += df2[k];
           }
           T val, base;
-          kern_value_base_fast(kind, r2, val, base);
+          if (kind == K_SPLINE) {
+            val = T(1);
+#pragma unroll
+            for (int k = 0; k < DCAP; ++k) val *= k < d ? spline_factor(xi[k], uj[col * ldu + k]) : T(1);
+            base = T(0);
+          } else {
+            kern_value_base_fast(kind, r2, val, base);
+          }
           if (gi == gj) {
             g_noise += wij;
             g_os += wij * val;
@@ -318,7 +337,7 @@ template <typename T>
 int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, const T *alpha, const T *X, int n,
                    int d, const T *ell, const T *oscale, double *grad, T *Kinv, int64_t ldk, int64_t strideK,
                    T *kinv_diag, void *partials, int q, void *stream) {
-  PLMC_REQUIRE(kind >= 0 && kind <= 3, "unknown kernel kind");
+  PLMC_REQUIRE(kind >= 0 && kind <= 4, "unknown kernel kind");
   PLMC_REQUIRE(W && alpha && X && ell && grad && partials, "null pointer");
   PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0 && ldw % NB == 0 && n <= n_pad && n > n_pad - NB, "n_pad must be plmc_pad(n)");
   PLMC_REQUIRE(d > 0 && d <= MAX_DIM && q > 0, "need 0<d<=plmc_max_dim(), q>0");

@@ -8,7 +8,7 @@ provided here as thin modules with the same names and parameter layout.
 """
 from . import settings, constraints, kernels, means, likelihoods, distributions, mlls, parallel, priors  # noqa: F401
 from .priors import NormalPrior, MultivariateNormalPrior  # noqa: F401
-from .kernels import RBFKernel, MaternKernel, ScaleKernel, MultitaskKernel, LCMKernel, IndexKernel  # noqa: F401
+from .kernels import RBFKernel, MaternKernel, SplineKernel, ScaleKernel, MultitaskKernel, LCMKernel, IndexKernel  # noqa: F401
 from .means import ZeroMean, ConstantMean, MultitaskMean, LinearMean, PolynomialMean  # noqa: F401
 from .likelihoods import GaussianLikelihood, MultitaskGaussianLikelihood  # noqa: F401
 from .distributions import MultivariateNormal, MultitaskMultivariateNormal  # noqa: F401

@@ -412,12 +412,12 @@ def exact_posterior(kind, X, ell, oscale, noise, y, Xs, full_cov=False):
     z = aug[:, :, 0]
     V = aug[:, :, 1:]
     mean = torch.einsum("qis,qi->qs", V, z)
-    os_ = torch.ones(q, dtype=dt, device=dev) if oscale is None else osc
     if full_cov:
         Kss = dense_cross(kind, Xsc, Xsc, ellc, osc)
         cov = Kss - V.transpose(-1, -2) @ V
         return mean, cov
-    var = os_[:, None] - (V * V).sum(1)
+    from .kernels import prior_diagonal
+    var = prior_diagonal(kind, Xsc, osc, q) - (V * V).sum(1)          # k(x*, x*) = 1 for the stationary kinds
     return mean, var
 
 

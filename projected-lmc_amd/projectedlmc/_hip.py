@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PLMC_LIB: dev override (a variant build of the same library, tools/wb_race_probe.py); never a fallback
 LIB_PATH = os.environ.get("PLMC_LIB") or os.path.join(_HERE, "libplmc_hip.so")
 
-KIND = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3}
+KIND = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3, "spline": 4}
 
 _c = ctypes
 _P = _c.c_void_p

@@ -41,13 +41,13 @@ class Kernel(torch.nn.Module):
             self.raw_lengthscale.copy_(raw.expand_as(self.raw_lengthscale))
 
     # -- descriptor pieces consumed by the engine
-    def _ell(self, d):
+    def _ell(self, d, like=None):
         """(q, d) lengthscales (q = prod(batch_shape) or 1)."""
         ell = self.lengthscale.reshape(-1, self.lengthscale.shape[-1])
         return ell.expand(ell.shape[0], d) if ell.shape[-1] != d else ell
 
-    def _pieces(self, d):
-        return self.kind, self._ell(d), None
+    def _pieces(self, d, like=None):
+        return self.kind, self._ell(d, like), None
 
     def select(self, x):
         if self.active_dims is not None and len(self.active_dims) != x.shape[-1]:
@@ -57,7 +57,7 @@ class Kernel(torch.nn.Module):
     def forward(self, x1, x2=None, **params):
         x1 = self.select(x1)
         x2 = x1 if x2 is None else self.select(x2)
-        kind, ell, osc = self._pieces(x1.shape[-1])
+        kind, ell, osc = self._pieces(x1.shape[-1], x1)
         return LazyKernel(kind, x1, x2, ell, osc, self.batch_shape)
 
 
@@ -75,6 +75,31 @@ class MaternKernel(Kernel):
         super().__init__(**kwargs)
         self.nu = nu
         self.kind = _MATERN_KIND[nu]
+
+
+class SplineKernel(Kernel):
+    """The reference's SplineKernel (projected_lmc.py:26-36): k(x, x') = prod_k [1 + m M + m^2 (M - m / 3) / 2] with
+    m = min(x_k, x'_k), M = max(x_k, x'_k); no lengthscale, k(x, x) = prod_k (1 + x_k^2 + x_k^3 / 3).  On the HIP path it
+    is kernel kind "spline" of the assembly / cross / gradient kernels (exact GP and projected models; the dense-LMC and
+    variational engines take the stationary kinds only)."""
+    has_lengthscale = False
+    kind = "spline"
+    is_stationary = True                      # as declared by the reference
+
+    def _ell(self, d, like=None):
+        q = max(1, int(self.batch_shape.numel()))
+        if like is None:
+            return torch.ones(q, d)
+        return torch.ones(q, d, dtype=like.dtype, device=like.device)
+
+
+def prior_diagonal(kind, x, oscale, q):
+    """k(x, x) per latent, (q, n): 1 for the stationary kinds, prod_k (1 + x_k^2 + x_k^3 / 3) for the spline kernel."""
+    if kind == "spline":
+        dg = (1 + x ** 2 + x ** 3 / 3).prod(dim=-1).reshape(1, -1).expand(q, -1)
+    else:
+        dg = torch.ones(q, x.shape[-2], dtype=x.dtype, device=x.device)
+    return dg if oscale is None else dg * oscale.reshape(-1, 1)
 
 
 class ScaleKernel(Kernel):
@@ -95,8 +120,8 @@ class ScaleKernel(Kernel):
         with torch.no_grad():
             self.raw_outputscale.copy_(self.raw_outputscale_constraint.inverse_transform(value).expand_as(self.raw_outputscale))
 
-    def _pieces(self, d):
-        kind, ell, _ = self.base_kernel._pieces(d)
+    def _pieces(self, d, like=None):
+        kind, ell, _ = self.base_kernel._pieces(d, like if like is not None else self.raw_outputscale)
         return kind, ell, self.outputscale.reshape(-1)
 
 
@@ -130,8 +155,7 @@ class LazyKernel:
 
     def diagonal(self, *args, **kwargs):
         q = self.ell.shape[0]
-        os_ = torch.ones(q, dtype=self.dtype, device=self.device) if self.oscale is None else self.oscale
-        dg = os_[:, None].expand(q, self.x1.shape[-2])
+        dg = prior_diagonal(self.kind, self.x1.to(self.ell.dtype), self.oscale, q)
         if self.noise is not None:
             dg = dg + self.noise.reshape(-1, 1)
         return dg.reshape(*self.batch_shape, -1)
