@@ -100,6 +100,10 @@ int plmc_assemble_cross_f64(int kind, const double *X, int n, const double *Xs, 
  * (the identity rides along as further right-hand sides) -- the first half of the Khat^-1 that
  * `loss.backward()` needs (experiments.py:270).  No initialisation of those
  * columns is required.
+ * with_inverse == 2: additionally accumulate Khat^-1 = W^T W group by group while the sweep runs (the second half of
+ * that work, as filler beside the latency-bound end of the factorisation): tile (ib < jb) of Khat^-1 is left in the
+ * strictly LOWER triangle of the square part at block (jb, ib) -- never read otherwise -- and the diagonal tiles in the
+ * last n_pad/NB blocks of Vd.  plmc_grad_tiles_* then turns it into the MLL gradient in one HBM-bound pass.
  */
 int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd,
                    double *logdet, int *info, int with_inverse, int q, void *stream);
@@ -120,6 +124,18 @@ int plmc_wt_matvec_f32(const float *W, int64_t n_pad, int64_t ldw, int64_t strid
                        float *alpha, int q, void *stream);
 int plmc_wt_matvec_f64(const double *W, int64_t n_pad, int64_t ldw, int64_t strideW, const double *z,
                        double *alpha, int q, void *stream);
+
+/*
+ * MLL gradient from the Khat^-1 a sweep with with_inverse = 2 accumulated (same outputs as plmc_kinv_grad_*: grad, and
+ * optionally kinv_diag; partials: the same scratch): (alpha alpha^T - Khat^-1) o dKhat/dtheta reduced per tile from X in
+ * LDS, one read of the stored tiles.  A, Vd: the buffers of that sweep.
+ */
+int plmc_grad_tiles_f32(int kind, const float *A, int64_t n_pad, int64_t lda, int64_t strideA, const float *Vd,
+                        const float *alpha, const float *X, int n, int d, const float *ell, const float *oscale,
+                        double *grad, float *kinv_diag, void *partials, int q, void *stream);
+int plmc_grad_tiles_f64(int kind, const double *A, int64_t n_pad, int64_t lda, int64_t strideA, const double *Vd,
+                        const double *alpha, const double *X, int n, int d, const double *ell, const double *oscale,
+                        double *grad, double *kinv_diag, void *partials, int q, void *stream);
 
 /*
  * Batched "TN" product on the tile engine:  C[b] (=, +=, -=) A[b]^T B[b]  with A: K x M and B: K x N, both stored

@@ -17,7 +17,7 @@ char *err_buf() {
 static const char *kProfNames[PK_COUNT] = {"k_assemble", "k_write_rhs", "k_assemble_cross", "k_diag",   "k_panel",
                                            "k_trail",    "k_wdiag",     "k_trtri_row",      "k_extract_col",
                                            "k_wt_matvec", "k_kinv_grad", "k_reduce_grad", "k_kernel_vjp",
-                                           "sweep_total", "k_trail_row", "k_trail_head", "k_gpanel"};
+                                           "sweep_total", "k_trail_row", "k_trail_head", "k_gpanel", "k_kacc", "k_grad_tiles"};
 struct ProfRec { int id; hipEvent_t a, b; double flops, bytes; };
 static unsigned g_prof_mask = 0;          // bit i: bracket kernel class i
 static std::vector<ProfRec> g_recs;
@@ -48,32 +48,24 @@ const Knobs &knobs() {
 
 // ---- helper stream + ordering events for the look-ahead of the blocked sweep (one per device,
 // created on first use; together with the profiler record this is all the process-global state).
-static hipStream_t g_side[64] = {nullptr};
-static hipStream_t g_side2[64] = {nullptr};
-static hipEvent_t g_sync[64][8] = {{nullptr}};
+static hipStream_t g_side[64][3] = {{nullptr}};
+static hipEvent_t g_sync[64][16] = {{nullptr}};
+// which: 0 = the chain (highest priority: its small launches must get CU slots ahead of queued bulk tiles), 1 = the group
+// panel + head rows (high), 2 = the K^-1 accumulation (default priority: filler work)
 hipStream_t side_stream(int which) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (which == 1) {                    // second helper: the inverse-factor chain of the sweep
-    if (!g_side2[dev]) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      if (hipStreamCreateWithPriority(&g_side2[dev], hipStreamNonBlocking, hi) != hipSuccess) g_side2[dev] = nullptr;
-    }
-    return g_side2[dev];
-  }
-  if (!g_side[dev]) {
-    // highest priority: the latency-bound chain must get CU slots ahead of the queued tail tiles
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || which < 0 || which > 2) return nullptr;
+  if (!g_side[dev][which]) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (hipStreamCreateWithPriority(&g_side[dev], hipStreamNonBlocking, hi) != hipSuccess) g_side[dev] = nullptr;
+    if (hipStreamCreateWithPriority(&g_side[dev][which], hipStreamNonBlocking, which == 2 ? lo : hi) != hipSuccess) g_side[dev][which] = nullptr;
   }
-  return g_side[dev];
+  return g_side[dev][which];
 }
 hipEvent_t sync_event(int idx) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  hipEvent_t &e = g_sync[dev][idx & 7];
+  hipEvent_t &e = g_sync[dev][idx & 15];
   if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
   return e;
 }

@@ -236,6 +236,37 @@ __global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, i
     }
 }
 
+// K^-1 accumulation inside the sweep (with_inverse = 2).  Khat^-1 = W^T W = sum over groups of W[R]^T W[R] (R = the block
+// rows of one group): as soon as the rows R of the inverse factor are final, their rank-(128 G) contribution goes into
+// the K^-1 tiles (ib <= jb < g1) -- bulk work that is largest for the LAST groups, where the trailing updates of the
+// sweep have shrunk and the GPU would otherwise idle behind the chain.  Only rows l >= jb contribute (W[l][jb] = 0 for
+// l < jb), so tiles with jb inside the group take a shorter range and are written for the first time (plain store).
+// Storage (no extra buffer): tile (ib < jb) lives in the strictly lower triangle of the factor buffer's square part,
+// at block (jb, ib) -- the lower triangle is never read by anything else -- and the diagonal tiles (ib == jb) in a
+// strip of the Vd scratch (Kd, leading dimension NB).  grid (g1 (g1 + 1) / 2, q).
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_kacc(T *A, int64_t lda, int64_t strideA, const T *__restrict__ W,
+                                                    int64_t ldw, int64_t strideW, T *Kd, int64_t strideKd, int g0, int g1) {
+  __shared__ __align__(16) T smem[tile_smem_elems<T>()];
+  const int lat = blockIdx.y, t = blockIdx.x;
+  int jb = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while ((jb + 1) * (jb + 2) / 2 <= t) ++jb;
+  while (jb * (jb + 1) / 2 > t) --jb;
+  const int ib = t - jb * (jb + 1) / 2;
+  const bool first = jb >= g0;
+  const int r0 = first ? jb : g0;
+  const T *Wl = W + (int64_t)lat * strideW + (int64_t)r0 * NB * ldw;
+  Acc<T> acc;
+  acc.zero();
+  tile_mainloop<T, false, false>(acc, Wl + (int64_t)ib * NB, ldw, Wl + (int64_t)jb * NB, ldw, (g1 - r0) * NB, smem);
+  T *C;
+  int64_t ldc;
+  if (ib == jb) { C = Kd + (int64_t)lat * strideKd + (int64_t)ib * NB * NB; ldc = NB; }
+  else { C = A + (int64_t)lat * strideA + (int64_t)jb * NB * lda + (int64_t)ib * NB; ldc = lda; }
+  if (first) tile_writeback<T, WB_STORE>(acc, C, ldc, smem);
+  else tile_writeback<T, WB_ADD>(acc, C, ldc, smem);
+}
+
 // ----------------------------------------------------------------------------------------------
 // z[lat][i] = A[i][n_pad + c];  quad[lat] = sum z^2 (double).  grid (q).
 template <typename T>
@@ -363,6 +394,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   T *const Vg2[2] = {Wg + (int64_t)GMAX * NB * LDG, Wg + 2 * (int64_t)GMAX * NB * LDG};
   T *const Ph = Wg + 3 * (int64_t)GMAX * NB * LDG;                      // panel buffer of the head columns (ld LDG)
   T *const Pbulk = Ph + (int64_t)GMAX * NB * LDG;                       // panel buffer of the other columns (ld lda)
+  T *const Kd = Vd + strideV - (int64_t)m * NB * NB;                    // diagonal tiles of the accumulated K^-1: last m blocks
+  const bool kacc_on = with_inverse == 2;
   T *const WA = with_inverse ? A + wcol0 : (T *)nullptr;                // inverse-factor columns of the factor buffer
 
   const Knobs &kn = knobs();                            // dev knobs: read once per process (api.hip)
@@ -459,7 +492,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // whole-sweep bracket on the caller's stream (the per-kernel records of overlapped kernels add up to
   // more than the wall time once the look-ahead runs the chain beside the trailing update)
   const double npd = (double)n_pad;
-  ProfScope whole(PK_SWEEP, st, q * (with_inverse ? 2.0 : 1.0) * npd * npd * npd / 3.0, 0.0);
+  ProfScope whole(PK_SWEEP, st, q * (with_inverse == 2 ? 3.0 : (with_inverse ? 2.0 : 1.0)) * npd * npd * npd / 3.0, 0.0);
   // tiles of the diagonal-block outputs that k_diag leaves alone (they are read as parts of full 128 x 128 operands)
   hipLaunchKernelGGL(k_zero_diag_out<T>, dim3(m > GMAX ? m : GMAX, q), dim3(NTHREADS), 0, st, Vd, strideV, m, Wg, (int64_t)LDG,
                      strideV, (int64_t)NB * LDG + NB, GMAX);
@@ -504,10 +537,24 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
                        strideA);
   };
 
+  auto kacc = [&](int gi, hipStream_t s) {
+    if (!kacc_on) return;
+    const int g0 = G0(gi), g1 = G0(gi + 1);
+    const int nt = g1 * (g1 + 1) / 2;
+    double fl = 0.0;
+    for (int jb = 0; jb < g1; ++jb) fl += (jb + 0.5) * 2.0 * nb * nb * (double)(g1 - (jb >= g0 ? jb : g0)) * nb;   // diagonal tiles: half
+    ProfScope ps(PK_KACC, s, q * fl, q * (2.0 * nt - (double)(g1 - g0) * (g0 + g1 + 1) / 2.0) * nb * nb * esz);
+    hipLaunchKernelGGL((k_kacc<T>), dim3(nt, q), dim3(NTHREADS), bulk_lds, s, A, lda, strideA, (const T *)WA, lda, strideA, Kd, strideV, g0, g1);
+  };
+
   hipStream_t C = serial ? nullptr : side_stream(), H = serial ? nullptr : side_stream(1);
+  // the K^-1 accumulation rides on the caller's stream behind the tail (e_tail is recorded before it, so nothing on the
+  // critical path waits for it).  A stream of its own shared a hardware queue with one of the others (HIP maps streams
+  // onto four hardware queues; with the gradient stream of the Python layer this library already uses four) and
+  // serialised the chain behind bulk launches: sweep + accumulation took exactly the sum of the two.
   hipEvent_t e_entry = sync_event(0), e_v = sync_event(1), e_gh = sync_event(2), e_p = sync_event(3), e_hd = sync_event(4),
-             e_tail = sync_event(5), e_doneC = sync_event(6), e_doneH = sync_event(7);
-  const bool la = C && H && e_entry && e_v && e_gh && e_p && e_hd && e_tail && e_doneC && e_doneH && ng > 2;
+             e_tail = sync_event(5), e_doneC = sync_event(6), e_doneH = sync_event(7), e_doneK = sync_event(8);
+  const bool la = C && H && e_entry && e_v && e_gh && e_p && e_hd && e_tail && e_doneC && e_doneH && e_doneK && ng > 2;
   if (!la) {
     // one stream: chain -> transpose -> group panel over every column -> trailing update of every row below
     for (int gi = 0; gi < ng; ++gi) {
@@ -516,6 +563,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       vtrans(gi, st);
       gpanel(g0, g1 - g0, cm_buf(g1, m - g1, Taug, 0, g0), Vg2[gi & 1], st, 0);
       update(g1, m - g1, g0, g1 - 1, cm_buf(g1, m - g1, Taug, 0, g1), st, PK_TRAIL);
+      kacc(gi, st);
     }
     return finish();
   }
@@ -558,11 +606,13 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     (void)hipStreamWaitEvent(st, e_gh, 0);
     update(g2, m - g2, g0, g1 - 1, cm_buf(g2, m - g2, Taug, 0, g1), st, PK_TRAIL);         // tail: rows below R1
     (void)hipEventRecord(e_tail, st);
+    kacc(gi, st);            // rows R0 of the inverse factor are final (e_p: panel copy; e_gh is behind vtrans): filler work
   }
   (void)hipEventRecord(e_doneC, C);
   (void)hipEventRecord(e_doneH, H);
   (void)hipStreamWaitEvent(st, e_doneC, 0);
   (void)hipStreamWaitEvent(st, e_doneH, 0);
+
   return finish();
 }
 
@@ -602,7 +652,7 @@ int w_diag_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, T *kinv
 
 extern "C" {
 int64_t plmc_vd_blocks(int64_t n_pad, int64_t lda) {
-  return n_pad / plmc::NB + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ((lda + plmc::NB - 1) / plmc::NB);
+  return 2 * (n_pad / plmc::NB) + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ((lda + plmc::NB - 1) / plmc::NB);
 }
 int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet,
                    int *info, int with_inverse, int q, void *stream) {

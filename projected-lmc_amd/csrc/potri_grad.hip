@@ -333,6 +333,130 @@ __global__ __launch_bounds__(RED_NT) void k_reduce_grad(const double *__restrict
   }
 }
 
+// ---- gradient pass over a K^-1 that the sweep accumulated (plmc_potrf_* with_inverse = 2; storage: potrf.hip, k_kacc).
+// HBM-bound: one read of the q n^2 / 2 stored elements; per upper tile the same sums as the fused epilogue above,
+//     g[k] += wt os w base df_k^2,  g_os += wt w val,  g_noise += w on the diagonal,   w = alpha_i alpha_j - Kinv_ij,
+// but with the tile coming from memory there are no accumulators to keep alive: thread = one column of the tile (its
+// scaled inputs in registers) x 64 rows (row inputs are wave-uniform LDS broadcasts); loads are whole 512-byte rows.
+// Same partials layout and fixed-order reduction (k_reduce_grad) as k_kinv_grad.  grid (m (m + 1) / 2 * q).
+template <typename T, int DCAP>
+__global__ __launch_bounds__(NTHREADS) void k_grad_tiles(int kind, const T *__restrict__ A, int64_t n_pad, int64_t lda, int64_t strideA,
+                                                         const T *__restrict__ Kd, int64_t strideKd, const T *__restrict__ alpha,
+                                                         const T *__restrict__ X, int n, int d, const T *__restrict__ ell,
+                                                         const T *__restrict__ oscale, T *kinv_diag, double *__restrict__ partials,
+                                                         int nlat) {
+  const int m = (int)(n_pad / NB);
+  const int w = blockIdx.x, lat = w % nlat, t = w / nlat;
+  int jb = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while ((jb + 1) * (jb + 2) / 2 <= t) ++jb;
+  while (jb * (jb + 1) / 2 > t) --jb;
+  const int ib = t - jb * (jb + 1) / 2;
+  __shared__ T ui[NB][DCAP + 1];
+  __shared__ T ai[NB];
+  __shared__ double red[4][GP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T *el = ell + (int64_t)lat * d;
+  for (int e = tid; e < NB * DCAP; e += NTHREADS) {
+    const int r = e / DCAP, k = e % DCAP, gi = ib * NB + r;
+    ui[r][k] = (k < d && gi < n) ? X[(int64_t)gi * d + k] / el[k] : T(0);
+  }
+  if (tid < NB) ai[tid] = alpha[(int64_t)lat * n_pad + ib * NB + tid];
+  const int col = tid & (NB - 1), rh = tid >> 7;                    // column of the tile, row parity
+  const int gj = jb * NB + col;
+  T uj[DCAP];
+#pragma unroll
+  for (int k = 0; k < DCAP; ++k) uj[k] = (k < d && gj < n) ? X[(int64_t)gj * d + k] / el[k] : T(0);
+  const T a_j = alpha[(int64_t)lat * n_pad + gj];
+  const T os = oscale ? oscale[lat] : T(1);
+  const T *Kt;
+  int64_t ldk;
+  if (ib == jb) { Kt = Kd + (int64_t)lat * strideKd + (int64_t)ib * NB * NB; ldk = NB; }
+  else { Kt = A + (int64_t)lat * strideA + (int64_t)jb * NB * lda + (int64_t)ib * NB; ldk = lda; }
+  __syncthreads();
+  T g[DCAP];
+#pragma unroll
+  for (int k = 0; k < DCAP; ++k) g[k] = T(0);
+  T g_noise = T(0), g_os = T(0);
+#pragma unroll 4
+  for (int rr = 0; rr < NB / 2; ++rr) {
+    const int row = 2 * rr + rh, gi = ib * NB + row;
+    const T kin = Kt[(int64_t)row * ldk + col];
+    if (kinv_diag && gi == gj) kinv_diag[(int64_t)lat * n_pad + gi] = kin;
+    const bool live = gi < n && gj < n && gj >= gi;
+    T wv = ai[row] * a_j - kin;
+    if (live && gi == gj) g_noise += wv;
+    wv = live ? (gj > gi ? T(2) * wv : wv) : T(0);
+    T df[DCAP];
+    T r2 = T(0), sp = T(1);
+#pragma unroll
+    for (int k = 0; k < DCAP; ++k) {
+      df[k] = ui[row][k] - uj[k];
+      r2 += df[k] * df[k];
+      if (kind == K_SPLINE) sp *= spline_factor(ui[row][k], uj[k]);
+    }
+    T val, base;
+    if (kind == K_SPLINE) { val = sp; base = T(0); }
+    else kern_value_base_fast(kind, r2, val, base);
+    g_os += wv * val;
+    const T c = wv * os * base;
+#pragma unroll
+    for (int k = 0; k < DCAP; ++k) g[k] += c * df[k] * df[k];
+  }
+  auto wave_sum = [&](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+  };
+#pragma unroll
+  for (int k = 0; k < DCAP; ++k) {
+    double s = wave_sum((double)g[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  {
+    double s = wave_sum((double)g_noise);
+    if (lane == 0) red[wave][MAX_DIM] = s;
+    s = wave_sum((double)g_os);
+    if (lane == 0) red[wave][MAX_DIM + 1] = s;
+  }
+  __syncthreads();
+  double *out = partials + (((int64_t)lat * m + ib) * m + jb) * GP;
+  if (tid < GP) {
+    const bool lv = tid < DCAP || tid >= MAX_DIM;
+    out[tid] = lv ? red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid] : 0.0;
+  }
+}
+
+template <typename T>
+int grad_tiles_impl(int kind, const T *A, int64_t n_pad, int64_t lda, int64_t strideA, const T *Vd, const T *alpha, const T *X, int n, int d,
+                    const T *ell, const T *oscale, double *grad, T *kinv_diag, void *partials, int q, void *stream) {
+  PLMC_REQUIRE(kind >= 0 && kind <= 4, "unknown kernel kind");
+  PLMC_REQUIRE(A && Vd && alpha && X && ell && grad && partials, "null pointer");
+  PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0 && lda % NB == 0 && n <= n_pad && n > n_pad - NB, "n_pad must be plmc_pad(n)");
+  PLMC_REQUIRE(d > 0 && d <= MAX_DIM && q > 0, "need 0<d<=plmc_max_dim(), q>0");
+  hipStream_t st = (hipStream_t)stream;
+  const int m = (int)(n_pad / NB);
+  const int64_t strideV = plmc_vd_blocks(n_pad, lda) * (int64_t)NB * NB;
+  const T *Kd = Vd + strideV - (int64_t)m * NB * NB;                  // last m blocks of the scratch: diagonal K^-1 tiles
+  double *part = reinterpret_cast<double *>(partials);
+  const dim3 grid(q * (m * (m + 1) / 2)), block(NTHREADS);
+#define PLMC_LAUNCH_GT(DC) \
+  hipLaunchKernelGGL((k_grad_tiles<T, DC>), grid, block, 0, st, kind, A, n_pad, lda, strideA, Kd, strideV, alpha, X, n, d, ell, oscale, kinv_diag, part, q)
+  {
+    const double np = (double)n_pad;
+    ProfScope ps(PK_GRAD_TILES, st, 0.0, q * (np * np / 2) * sizeof(T));
+    if (d <= 4) PLMC_LAUNCH_GT(4);
+    else if (d <= 8) PLMC_LAUNCH_GT(8);
+    else if (d <= 16) PLMC_LAUNCH_GT(16);
+    else PLMC_LAUNCH_GT(32);
+  }
+#undef PLMC_LAUNCH_GT
+  {
+    ProfScope ps(PK_REDUCE, st, 0.0, (double)plmc_grad_scratch_bytes(n_pad, q) / 2);
+    hipLaunchKernelGGL(k_reduce_grad<T>, dim3(q), dim3(RED_NT), 0, st, part, m, d, ell, grad);
+  }
+  return launch_status(__func__);
+}
+
 template <typename T>
 int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, const T *alpha, const T *X, int n,
                    int d, const T *ell, const T *oscale, double *grad, T *Kinv, int64_t ldk, int64_t strideK,
@@ -375,6 +499,16 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
 }  // namespace plmc
 
 extern "C" {
+int plmc_grad_tiles_f32(int kind, const float *A, int64_t n_pad, int64_t lda, int64_t strideA, const float *Vd, const float *alpha,
+                        const float *X, int n, int d, const float *ell, const float *oscale, double *grad, float *kinv_diag,
+                        void *partials, int q, void *stream) {
+  return plmc::grad_tiles_impl<float>(kind, A, n_pad, lda, strideA, Vd, alpha, X, n, d, ell, oscale, grad, kinv_diag, partials, q, stream);
+}
+int plmc_grad_tiles_f64(int kind, const double *A, int64_t n_pad, int64_t lda, int64_t strideA, const double *Vd, const double *alpha,
+                        const double *X, int n, int d, const double *ell, const double *oscale, double *grad, double *kinv_diag,
+                        void *partials, int q, void *stream) {
+  return plmc::grad_tiles_impl<double>(kind, A, n_pad, lda, strideA, Vd, alpha, X, n, d, ell, oscale, grad, kinv_diag, partials, q, stream);
+}
 int64_t plmc_grad_scratch_bytes(int64_t n_pad, int q) {
   int64_t m = n_pad / plmc::NB;
   return m * m * (int64_t)q * plmc::GP * (int64_t)sizeof(double);

@@ -115,9 +115,10 @@ def _contig(t, dtype=None):
     return t.contiguous()
 
 
-def factorize(kind, X, ell, oscale, noise, rhs, ws, Xs=None):
+def factorize(kind, X, ell, oscale, noise, rhs, ws, Xs=None, kacc=False):
     """Assemble Khat (+ rhs / cross-covariance columns) and run the blocked Cholesky.
-    rhs: (q, nrhs, n) or None.  Returns nothing; results live in ws (A, Vd, logdet, info)."""
+    rhs: (q, nrhs, n) or None.  Returns nothing; results live in ws (A, Vd, logdet, info).
+    kacc: also accumulate Khat^-1 = W^T W inside the sweep (plmc_potrf with_inverse = 2; needs ws.with_inverse)."""
     L = _hip.lib()
     dt, dev = ws.dtype, ws.device
     st = _hip.stream_ptr(dev)
@@ -132,7 +133,16 @@ def factorize(kind, X, ell, oscale, noise, rhs, ws, Xs=None):
         L.call("plmc_assemble_cross", dt, k, _hip.ptr(X), n, _hip.ptr(Xs), Xs.shape[0], d, _hip.ptr(ell),
                _hip.ptr(oscale), _hip.ptr(ws.A), ws.lda, ws.strideA, ws.n_pad + nrhs, ws.n_pad, q, st)
     L.call("plmc_potrf", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.naug, ws.strideA, _hip.ptr(ws.Vd),
-           _hip.ptr(ws.logdet), _hip.ptr(ws.info), int(ws.with_inverse), q, st)
+           _hip.ptr(ws.logdet), _hip.ptr(ws.info), (2 if kacc else 1) if ws.with_inverse else 0, q, st)
+
+
+def sweep_accumulates_kinv():
+    """PLMC_KINV_IN_SWEEP=1: the sweep accumulates Khat^-1 = W^T W group by group (plmc_potrf with_inverse = 2) and the
+    gradient is one HBM-bound pass over it (plmc_grad_tiles).  Default: one fused K^-1 + gradient kernel behind the
+    sweep (plmc_kinv_grad) on the gradient stream.  Measured on MI355X (n = 8192, fp32; ms/step fused vs in-sweep):
+    q = 8 37.4 / 37.4, q = 4 19.6 / 20.3, q = 2 11.2 / 11.7, q = 1 7.6 / 8.3 -- the accumulation does not hide behind the
+    latency-bound end of the sweep, it slows the chain it runs beside, so it stays an option."""
+    return os.environ.get("PLMC_KINV_IN_SWEEP", "0") == "1"
 
 
 def factorize_checked(kind, X, ell, oscale, noise, rhs, ws, Xs=None):
@@ -232,9 +242,11 @@ class ExactLatentLogProb(torch.autograd.Function):
         grad = table if table is not None else (torch.empty(q, d + 2, dtype=torch.float64, device=dev) if need_grad else None)
         check = settings.check_cholesky.on()
 
+        kacc = need_grad and sweep_accumulates_kinv()
+
         def enqueue(noise_eff):
             """factorisation + everything that consumes it; returns (logp, deferred pivot check)."""
-            factorize(kind, Xc, ellc, osc, noise_eff, yc.reshape(q, 1, n), ws)
+            factorize(kind, Xc, ellc, osc, noise_eff, yc.reshape(q, 1, n), ws, kacc=kacc)
             info = _DeferredInfo(ws) if check else None
             L.call("plmc_extract_col", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, 0, _hip.ptr(ws.z),
                    _hip.ptr(ws.quad), q, st)
@@ -250,9 +262,14 @@ class ExactLatentLogProb(torch.autograd.Function):
                     for t in (grad, Xc, ellc, osc):
                         if t is not None:
                             t.record_stream(gs)
-                L.call("plmc_kinv_grad", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW,
-                       _hip.ptr(ws.alpha), _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad),
-                       None, 0, 0, None, _hip.ptr(ws.partials), q, gst)
+                if kacc:
+                    L.call("plmc_grad_tiles", dt, _hip.KIND[kind], _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, _hip.ptr(ws.Vd),
+                           _hip.ptr(ws.alpha), _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad), None,
+                           _hip.ptr(ws.partials), q, gst)
+                else:
+                    L.call("plmc_kinv_grad", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW,
+                           _hip.ptr(ws.alpha), _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad),
+                           None, 0, 0, None, _hip.ptr(ws.partials), q, gst)
                 if gs is not None:
                     ws.pending = torch.cuda.Event()
                     ws.pending.record(gs)

@@ -31,6 +31,7 @@ _TYPED = {
     "plmc_w_diag": [_P, _L, _L, _L, _P, _I, _P],
     "plmc_gemm_tn": [_I, _I, _I, _I, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P],
     "plmc_kinv_grad": [_I, _P, _L, _L, _L, _P, _P, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P],
+    "plmc_grad_tiles": [_I, _P, _L, _L, _L, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     "plmc_lmc_assemble": [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P],
     "plmc_lmc_cross": [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _P],
     "plmc_lmc_kinv_grad": [_I, _P, _L, _L, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],

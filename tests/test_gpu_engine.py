@@ -54,6 +54,7 @@ def test_logprob_and_grad_fp64(eng, kind, n, d, q, use_os):
 @pytest.mark.parametrize("n,d,q,env", [(1300, 3, 2, None), (2100, 4, 8, None), (3300, 3, 2, None), (1300, 3, 2, "PLMC_SERIAL=1"),
                                        (2100, 4, 8, "PLMC_GRP=4"), (1300, 3, 2, "PLMC_GRP=3"), (2100, 4, 8, "PLMC_HALF_TILES=0"),
                                        (1300, 3, 2, "PLMC_HALF_TILES=1"), (1300, 3, 2, "PLMC_GRAD_STREAM=0"),
+                                       (1300, 3, 2, "PLMC_KINV_IN_SWEEP=1"), (2100, 4, 8, "PLMC_KINV_IN_SWEEP=1"),
                                        (1300, 3, 2, "PLMC_KINV_ORDER=1"), (1300, 3, 2, "PLMC_KINV_ORDER=0"),
                                        (1300, 3, 2, "PLMC_KINV_ORDER=5")])
 def test_multi_group_sweep_fp64(eng, n, d, q, env, monkeypatch):
@@ -62,7 +63,7 @@ def test_multi_group_sweep_fp64(eng, n, d, q, env, monkeypatch):
     off, other group sizes, half / full tiles for the small launches, the gradient stream and the tile order / general
     epilogue of the gradient kernel switched (the dev knobs must not change results)."""
     from projectedlmc import _hip
-    if env and env.startswith("PLMC_GRAD_STREAM"):
+    if env and env.startswith(("PLMC_GRAD_STREAM", "PLMC_KINV_IN_SWEEP")):
         monkeypatch.setenv(*env.split("="))                     # Python-level knob, read per call
     elif env:
         with _hip.knob(*env.split("=")):
