@@ -171,14 +171,21 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_lmc_kinv_grad(i
   __syncthreads();
   const int ldu = d + 1;
   const bool diag_tile = jb == ib;
+  // fp64 with more than 8 input dimensions: the lengthscale sums are taken GH = 8 dimensions per walk of the tile (the
+  // 128 accumulator registers leave no room for 16 or 32 more doubles at 2 waves per SIMD); the scatter terms and the
+  // outputscale sum are added in the first walk only.
+  constexpr int GH = (sizeof(T) == 8 && DCAP > 8) ? 8 : DCAP;
 #pragma unroll 1
   for (int i = 0; i < q; ++i) {
-    T gl[DCAP], go = T(0);
-#pragma unroll
-    for (int k = 0; k < DCAP; ++k) gl[k] = T(0);
     const T os_i = t.os[i];
     const T *invl = t.invl + i * d;
     const T *Bi = t.B + i * p * p;
+#pragma unroll 1
+    for (int k0 = 0; k0 < DCAP && (k0 == 0 || k0 < d); k0 += GH) {
+    const bool first = k0 == 0;
+    T gl[GH], go = T(0);
+#pragma unroll
+    for (int k = 0; k < GH; ++k) gl[k] = T(0);
 #pragma unroll 1
     for (int mt = 0; mt < 4; ++mt) {
 #define PLMC_PARK(M)                                                                                    \
@@ -199,34 +206,42 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_lmc_kinv_grad(i
           if (a >= 0 && b >= 0 && (!diag_tile || col >= row)) {
             const T kin = park[nt * NTHREADS * 4 + r];
             const T wij = ((diag_tile && col == row) ? T(1) : T(2)) * (ai[row] * a_j - kin);
-            if (i == 0 && a == b) atomicAdd(&gS[s * p + tt], (double)wij);
+            if (i == 0 && first && a == b) atomicAdd(&gS[s * p + tt], (double)wij);
             const T *xir = t.xi + row * ldu;
             T r2 = T(0);
+            if constexpr (GH == DCAP) {
 #pragma unroll
-            for (int k = 0; k < DCAP; ++k) {
-              const T df = k < d ? (xir[k] - xjc[k]) * invl[k] : T(0);
-              r2 += df * df;
+              for (int k = 0; k < DCAP; ++k) {
+                const T df = k < d ? (xir[k] - xjc[k]) * invl[k] : T(0);
+                r2 += df * df;
+              }
+            } else {
+#pragma unroll 4
+              for (int k = 0; k < d; ++k) { const T df = (xir[k] - xjc[k]) * invl[k]; r2 += df * df; }
             }
             T val, base;
             kern_value_base<T>(kind, r2, val, base);
             const T bst = Bi[s * p + tt];
-            atomicAdd(&gB[(i * p + s) * p + tt], (double)(wij * os_i * val));
-            go += wij * val * bst;
+            if (first) {
+              atomicAdd(&gB[(i * p + s) * p + tt], (double)(wij * os_i * val));
+              go += wij * val * bst;
+            }
             const T c = a != b ? wij * os_i * bst * base : T(0);
             // the differences are formed a second time instead of keeping DCAP squares alive across the kernel value
 #pragma unroll
-            for (int k = 0; k < DCAP; ++k) {
-              const T df = k < d ? (xir[k] - xjc[k]) * invl[k] : T(0);
+            for (int k = 0; k < GH; ++k) {
+              const T df = k0 + k < d ? (xir[k0 + k] - xjc[k0 + k]) * invl[k0 + k] : T(0);
               gl[k] += c * (df * df);
             }
           }
         }
       }
     }
-    atomicAdd(&gO[i], (double)go);
+    if (first) atomicAdd(&gO[i], (double)go);
 #pragma unroll
-    for (int k = 0; k < DCAP; ++k)
-      if (k < d) atomicAdd(&gL[i * d + k], (double)gl[k]);
+    for (int k = 0; k < GH; ++k)
+      if (k0 + k < d) atomicAdd(&gL[i * d + k0 + k], (double)gl[k]);
+    }
   }
   __syncthreads();
   double *out = partials + ((int64_t)ib * m + jb) * nacc;

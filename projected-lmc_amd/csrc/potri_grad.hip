@@ -122,7 +122,9 @@ __device__ __forceinline__ void grad_tile_small(const Acc<T> &acc, T *smem, T os
 // occupancy floor: fp32 with up to 8 input dimensions fits 128 registers (4 waves per SIMD, as the update kernels)
 template <typename T, int DCAP> constexpr int KG_MIN_WAVES = sizeof(T) == 8 ? 2 : (DCAP <= 8 ? 4 : (DCAP <= 16 ? 2 : 1));
 
-template <typename T, int DCAP>
+// SPLINE (general epilogue only): the product-form spline kernel gets its own instantiation, so that its extra live
+// values do not raise the register pressure (and the scratch) of the stationary kernels' code.
+template <typename T, int DCAP, bool SPLINE = false>
 __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad(int kind, const T *__restrict__ W, int64_t n_pad, int64_t ldw,
                                                          int64_t strideW, const T *__restrict__ alpha,
                                                          const T *__restrict__ X, int n, int d,
@@ -158,13 +160,19 @@ __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad
   // per-lane partial sums over the lane's 64 tile elements stay in T (fp32 on the fp32 path: 64 terms,
   // relative error ~4e-6, far inside the fp32 gradient tolerance); everything across lanes, waves and
   // tiles is reduced in fp64.
-  T g[DCAP];
-#pragma unroll
-  for (int k = 0; k < DCAP; ++k) g[k] = T(0);
   T g_noise = T(0), g_os = T(0);
+  auto wave_sum = [&](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+  };
+  double *red;                                         // [4][GP] per-wave sums, reduced across waves at the end
 
   if constexpr (DCAP <= 8) {
     typedef GradLds<DCAP> L;
+    T g[DCAP];
+#pragma unroll
+    for (int k = 0; k < DCAP; ++k) g[k] = T(0);
     static_assert(L::END <= tile_smem_elems<T>(), "gradient epilogue LDS plan");
     for (int e = tid; e < NB * DCAP; e += NTHREADS) {     // unused dimensions and rows beyond n are staged as zeros
       const int r = e / DCAP, k = e % DCAP;
@@ -195,14 +203,31 @@ __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad
       else PLMC_GRAD_TILE(K_SPLINE, false);
     }
 #undef PLMC_GRAD_TILE
+    __syncthreads();                                   // the sums reuse the staging area
+    red = reinterpret_cast<double *>(smem);
+#pragma unroll
+    for (int k = 0; k < DCAP; ++k) {
+      const double s = wave_sum((double)g[k]);
+      if (lane == 0) red[wave * GP + k] = s;
+    }
   } else {
   // d > 8: general tile code.  mt / nt are unrolled (static accumulator indices); the register r inside an MFMA tile
   // is picked with a select chain -- a runtime-indexed accumulator would be demoted to scratch memory.
+  // fp32 keeps the row's inputs, the squared differences and all DCAP lengthscale sums in registers (one pass over the
+  // tile).  fp64 (64 accumulator doubles = 128 registers at 2 waves per SIMD) walks the tile once per group of GH = 8
+  // dimensions with 8 sums live and reads the inputs from LDS where they are needed; the covariance value is
+  // recomputed per pass.  Either way nothing is spilled.
+  constexpr bool KEEP = sizeof(T) == 4;
+  constexpr int GH = KEEP ? DCAP : 8;
+  constexpr int KD = KEEP ? DCAP : 1;
   const int ldu = d + 1;
   T *ui = smem;                        // [128][ldu]
   T *uj = ui + NB * ldu;               // [128][ldu]
   T *ai = uj + NB * ldu;               // [128]
   T *aj = ai + NB;                     // [128]
+  red = reinterpret_cast<double *>(aj + NB);           // own area: filled pass by pass
+  static_assert((2 * NB * (MAX_DIM + 1) + 2 * NB) * sizeof(T) + 4 * GP * sizeof(double) <= tile_smem_elems<T>() * sizeof(T),
+                "general gradient epilogue LDS plan");
   for (int e = tid; e < NB * d; e += NTHREADS) {
     int r = e / d, k = e % d;
     int gi = ib * NB + r, gj = jb * NB + r;
@@ -215,71 +240,96 @@ __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad
     aj[tid] = alpha[(int64_t)lat * n_pad + jb * NB + tid];
   }
   __syncthreads();
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-      const int row = tile_row<T>(wm, mt, lane, r);
-      const int gi = ib * NB + row;
-      T xi[DCAP];
+  for (int k0 = 0; k0 < DCAP; k0 += GH) {
+    T g[GH];
 #pragma unroll
-      for (int k = 0; k < DCAP; ++k) xi[k] = k < d ? ui[row * ldu + k] : T(0);
-      const T a_i = ai[row];
+    for (int k = 0; k < GH; ++k) g[k] = T(0);
+    const bool first = k0 == 0;
+    if (first || (k0 < d && !SPLINE)) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int col = tile_col(wn, nt, lane);
-        const int gj = jb * NB + col;
-        const auto &av = acc.v[mt][nt];
-        const T kin = r == 0 ? av[0] : (r == 1 ? av[1] : (r == 2 ? av[2] : av[3]));
-        if (Kinv && gj >= gi) Kinv[(int64_t)lat * strideK + (int64_t)gi * ldk + gj] = kin;
-        if (kinv_diag && gi == gj) kinv_diag[(int64_t)lat * n_pad + gi] = kin;
-        if (gi < n && gj < n && gj >= gi) {
-          const T wij = a_i * aj[col] - kin;
-          T df2[DCAP];
-          T r2 = T(0);
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+          const int row = tile_row<T>(wm, mt, lane, r);
+          const int gi = ib * NB + row;
+          T xi[KD];
+          const T *uir = ui + row * ldu;
+          if constexpr (KEEP) {
 #pragma unroll
-          for (int k = 0; k < DCAP; ++k) {
-            T df = k < d ? xi[k] - uj[col * ldu + k] : T(0);
-            df2[k] = df * df;
-            r2 += df2[k];
+            for (int k = 0; k < DCAP; ++k) xi[k] = k < d ? uir[k] : T(0);
           }
-          T val, base;
-          if (kind == K_SPLINE) {
-            val = T(1);
+          const T a_i = ai[row];
 #pragma unroll
-            for (int k = 0; k < DCAP; ++k) val *= k < d ? spline_factor(xi[k], uj[col * ldu + k]) : T(1);
-            base = T(0);
-          } else {
-            kern_value_base_fast(kind, r2, val, base);
-          }
-          if (gi == gj) {
-            g_noise += wij;
-            g_os += wij * val;
-          } else {
-            const T c = T(2) * wij * os * base;          // symmetric pair (i,j),(j,i)
+          for (int nt = 0; nt < 4; ++nt) {
+            const int col = tile_col(wn, nt, lane);
+            const int gj = jb * NB + col;
+            const auto &av = acc.v[mt][nt];
+            const T kin = r == 0 ? av[0] : (r == 1 ? av[1] : (r == 2 ? av[2] : av[3]));
+            if (first) {
+              if (Kinv && gj >= gi) Kinv[(int64_t)lat * strideK + (int64_t)gi * ldk + gj] = kin;
+              if (kinv_diag && gi == gj) kinv_diag[(int64_t)lat * n_pad + gi] = kin;
+            }
+            if (gi < n && gj < n && gj >= gi) {
+              const T wij = a_i * aj[col] - kin;
+              const T *ujc = uj + col * ldu;
+              T df2[KD];
+              T r2 = T(0);
+              if constexpr (KEEP) {
 #pragma unroll
-            for (int k = 0; k < DCAP; ++k) g[k] += c * df2[k];
-            g_os += T(2) * wij * val;
+                for (int k = 0; k < DCAP; ++k) {
+                  T df = k < d ? xi[k] - ujc[k] : T(0);
+                  df2[k] = df * df;
+                  r2 += df2[k];
+                }
+              } else {
+#pragma unroll 4
+                for (int k = 0; k < d; ++k) { const T df = uir[k] - ujc[k]; r2 += df * df; }
+              }
+              T val, base;
+              if constexpr (SPLINE) {
+                val = T(1);
+                if constexpr (KEEP) {
+#pragma unroll
+                  for (int k = 0; k < DCAP; ++k) val *= k < d ? spline_factor(xi[k], ujc[k]) : T(1);
+                } else {
+#pragma unroll 4
+                  for (int k = 0; k < d; ++k) val *= spline_factor(uir[k], ujc[k]);
+                }
+                base = T(0);
+              } else {
+                kern_value_base_fast(kind, r2, val, base);
+              }
+              if (gi == gj) {
+                if (first) { g_noise += wij; g_os += wij * val; }
+              } else {
+                const T c = T(2) * wij * os * base;          // symmetric pair (i,j),(j,i)
+                if constexpr (KEEP) {
+#pragma unroll
+                  for (int k = 0; k < DCAP; ++k) g[k] += c * df2[k];
+                } else if constexpr (!SPLINE) {
+#pragma unroll
+                  for (int k = 0; k < GH; ++k) {
+                    const T df = k0 + k < d ? uir[k0 + k] - ujc[k0 + k] : T(0);
+                    g[k] += c * df * df;
+                  }
+                }
+                if (first) g_os += T(2) * wij * val;
+              }
+            }
           }
         }
       }
     }
+#pragma unroll
+    for (int k = 0; k < GH; ++k) {
+      const double s = wave_sum((double)g[k]);
+      if (lane == 0) red[wave * GP + k0 + k] = s;
+    }
   }
   }
 
-  // ---- workgroup reduction of the d+2 partial sums (wave shuffles, then LDS across 4 waves)
-  __syncthreads();
-  double *red = reinterpret_cast<double *>(smem);    // [4][GP]
-  auto wave_sum = [&](double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-  };
-#pragma unroll
-  for (int k = 0; k < DCAP; ++k) {
-    double s = wave_sum((double)g[k]);
-    if (lane == 0) red[wave * GP + k] = s;
-  }
+  // ---- noise / outputscale sums, then the reduction across the 4 waves
   {
     double s = wave_sum((double)g_noise);
     if (lane == 0) red[wave * GP + MAX_DIM] = s;
@@ -477,16 +527,16 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
   const int plain = knobs().kinv_order;
   const dim3 grid = plain >= 4 ? dim3(q * (m * (m + 1) / 2)) : plain ? dim3(m, m, q) : dim3(xcd_tri_grid(m, q)), block(NTHREADS);
   double *part = reinterpret_cast<double *>(partials);
-#define PLMC_LAUNCH_KG(DC)                                                                                          \
-  hipLaunchKernelGGL((k_kinv_grad<T, DC>), grid, block, 0, st, kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell,   \
+#define PLMC_LAUNCH_KG(DC, ...)                                                                                     \
+  hipLaunchKernelGGL((k_kinv_grad<T, DC, ##__VA_ARGS__>), grid, block, 0, st, kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, \
                      oscale, Kinv, ldk, strideK, kinv_diag, part, q, plain)
   {
     const double np = (double)n_pad;
     ProfScope ps(PK_KINV_GRAD, st, q * np * np * np / 3.0, q * (np * np / 2) * sizeof(T));
     if (d <= 4) PLMC_LAUNCH_KG(4);
     else if (d <= 8) PLMC_LAUNCH_KG(8);
-    else if (d <= 16) PLMC_LAUNCH_KG(16);
-    else PLMC_LAUNCH_KG(32);
+    else if (d <= 16) { if (kind == K_SPLINE) PLMC_LAUNCH_KG(16, true); else PLMC_LAUNCH_KG(16); }
+    else { if (kind == K_SPLINE) PLMC_LAUNCH_KG(32, true); else PLMC_LAUNCH_KG(32); }
   }
 #undef PLMC_LAUNCH_KG
   {

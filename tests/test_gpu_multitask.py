@@ -46,10 +46,13 @@ def _oracle_inputs(model, lik):
     return sd, ell, B, S, mc
 
 
-@pytest.mark.parametrize("model_type,kernel,rank", [("LMC", "RBFKernel", 0), ("LMC", "MaternKernel", 2),
-                                                    ("ICM", "RBFKernel", 0)])
-def test_exact_lmc_mll_and_gradients(plmc, model_type, kernel, rank):
-    n, d, p, q = 70, 3, 4, 2
+@pytest.mark.parametrize("model_type,kernel,rank,d", [("LMC", "RBFKernel", 0, 3), ("LMC", "MaternKernel", 2, 3),
+                                                      ("ICM", "RBFKernel", 0, 3),
+                                                      # more than 8 / more than 16 input dimensions: the gradient
+                                                      # epilogue takes the lengthscale sums 8 dimensions per tile walk
+                                                      ("LMC", "MaternKernel", 0, 12), ("LMC", "RBFKernel", 2, 20)])
+def test_exact_lmc_mll_and_gradients(plmc, model_type, kernel, rank, d):
+    n, p, q = 70, 4, 2
     X, Y = _data(n, d, p, seed=5)
     torch.manual_seed(3)
     lik = plmc.MultitaskGaussianLikelihood(num_tasks=p, rank=rank)
