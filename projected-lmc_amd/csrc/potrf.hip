@@ -29,7 +29,7 @@
 
 namespace plmc {
 
-constexpr int GMAX = 8;                       // largest group (block rows)
+constexpr int GMAX = 8;                       // largest group (block rows; 16 was measured: 4 groups at n = 8192 pipeline too coarsely, 36.8 -> 38.8 ms at q = 8)
 // slabs of 16 rows the chain kernels keep in flight (tile_mainloop_burst): fp32 all 8 of K = 128, fp64 4 (registers)
 template <typename T> constexpr int CHAIN_BURST = sizeof(T) == 8 ? 4 : 8;
 constexpr int LDG = (GMAX + 1) * NB;          // leading dimension of the group scratch matrices (Wg, Vg, Ph): an odd number of
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
   if constexpr (ROLE == 4) {                           // rank-128 update of the triangle, few latents (see k_panel)
     tile_mainloop_burst<T, MT, 4, CHAIN_BURST<T>>(acc, Ap, lda, Bp, ldc, depth, smem);
   } else if constexpr (ROLE == 2 && MT == 2) {         // look-ahead update of the next triangle: few tiles, critical path
-    tile_mainloop_burst<T, MT, 4, 4>(acc, Ap, lda, Bp, ldc, depth, smem);
+    tile_mainloop_burst<T, MT, 4, (sizeof(T) == 8 ? 4 : 8)>(acc, Ap, lda, Bp, ldc, depth, smem);
   } else {
     tile_mainloop<T, false, false, MT>(acc, Ap, lda, Bp, ldc, depth, smem);
   }
@@ -164,23 +164,32 @@ __global__ __launch_bounds__(NTHREADS, (sizeof(T) == 8 || HEAD ? 2 : 4)) void k_
     lds = cm.ldw;
     S = cm.W + (int64_t)lat * cm.strideW + (int64_t)g0 * NB * lds + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
   }
-  // head launch (latency-critical, few strips): one block row per workgroup, heavy rows first.  Bulk launch: rows
-  // y and G-1-y share a workgroup -- every workgroup then carries depth 128 (G + 1) instead of 128 .. 128 G, and the
-  // short products no longer dominate the launch (77 -> ~100 TF at q = 8)
-  const int y = blockIdx.y;
-  const int i0 = head ? G - 1 - y : G - 1 - y, i1 = head ? -1 : (y < G - 1 - y ? y : -1);
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    const int i = pass == 0 ? i0 : i1;
-    if (i < 0) break;
-    Acc<T> acc;
+  if constexpr (HEAD) {
+    // head launch (latency-critical, few strips; grid.y = 2 G): one 64-row half of one block row per workgroup, heavy
+    // rows first.  What bounds a workgroup here is the number of dependent global round trips (5-10 us each beside the
+    // bulk kernels), so the half tile keeps HEAD_BURST slabs in flight (the registers a full tile would need for that
+    // do not fit) and the launch has twice the workgroups.
+    constexpr int HEAD_BURST = sizeof(T) == 8 ? 4 : 8;
+    const int i = G - 1 - (int)blockIdx.y / 2, h0 = ((int)blockIdx.y & 1) * 64;
+    Acc<T, 2> acc;
     acc.zero();
-    if constexpr (HEAD)                                // latency-critical: four slabs in flight (tile_mainloop_burst)
-      tile_mainloop_burst<T, 4, 4, (sizeof(T) == 8 ? 2 : 4)>(acc, Vg + (int64_t)lat * strideVg + (int64_t)i * NB, ldv, S, lds, (i + 1) * NB, smem);
-    else
+    tile_mainloop_burst<T, 2, 4, HEAD_BURST>(acc, Vg + (int64_t)lat * strideVg + (int64_t)i * NB + h0, ldv, S, lds, (i + 1) * NB, smem);
+    tile_writeback<T, WB_STORE, 2>(acc, Pb + (int64_t)lat * strideP + ((int64_t)i * NB + h0) * ldp + (int64_t)t * NB, ldp, smem);
+  } else {
+    // bulk launch: rows y and G-1-y share a workgroup -- every workgroup then carries depth 128 (G + 1) instead of
+    // 128 .. 128 G, and the short products no longer dominate the launch (77 -> ~100 TF at q = 8)
+    const int y = blockIdx.y;
+    const int i0 = G - 1 - y, i1 = y < G - 1 - y ? y : -1;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      const int i = pass == 0 ? i0 : i1;
+      if (i < 0) break;
+      Acc<T> acc;
+      acc.zero();
       tile_mainloop<T, false, false>(acc, Vg + (int64_t)lat * strideVg + (int64_t)i * NB, ldv, S, lds, (i + 1) * NB, smem);
-    tile_writeback<T, WB_STORE>(acc, Pb + (int64_t)lat * strideP + (int64_t)i * NB * ldp + (int64_t)t * NB, ldp, smem);
-    __syncthreads();                   // staging buffer free before the second product refills it
+      tile_writeback<T, WB_STORE>(acc, Pb + (int64_t)lat * strideP + (int64_t)i * NB * ldp + (int64_t)t * NB, ldp, smem);
+      __syncthreads();                   // staging buffer free before the second product refills it
+    }
   }
 }
 
@@ -480,7 +489,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     {
       ProfScope ps(PK_GPANEL, s, q * (double)nt * prods * 2.0 * nb3, q * (double)nt * (prods + G) * nb * nb * esz);
       if (head)
-        hipLaunchKernelGGL((k_gpanel_rows<T, 1>), dim3(nt, G, q), dim3(NTHREADS), 0, s, (const T *)A, lda, strideA, g0, G, cm, Vg, (int64_t)LDG,
+        hipLaunchKernelGGL((k_gpanel_rows<T, 1>), dim3(nt, 2 * G, q), dim3(NTHREADS), 0, s, (const T *)A, lda, strideA, g0, G, cm, Vg, (int64_t)LDG,
                            strideV, Pb, ldp, strideV);
       else
         hipLaunchKernelGGL((k_gpanel_rows<T, 0>), dim3(nt, (G + 1) / 2, q), dim3(NTHREADS), bulk_lds, s, (const T *)A, lda, strideA, g0, G, cm, Vg,
@@ -527,6 +536,13 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       // right-looking inside the triangle: every remaining row of the group gets the rank-128 update of row r at once
       // (depth 128 per launch; a left-looking row update grows to depth 128 (G - 1) on ONE workgroup's critical path:
       // 10 -> 43 us per launch at G = 8).  W columns g0 .. r: column r is touched for the first time (plain store).
+      // Two ways of taking this launch off the chain's critical path were built and measured, and dropped:
+      //  - the updates on a second helper stream, ordered row by row with events: ~10 us per cross-stream hop on the GPU
+      //    and ~17 us per event call on the host (q = 1: sweep 5.3 -> 6.5 ms, step 7.3 -> 11.9 ms);
+      //  - one launch carrying this update AND the next diagonal block, whose workgroup applied the last rank-128
+      //    update of its block itself (two launches per block row instead of three): the extra round trips of that
+      //    prologue beside the bulk kernels made the fused launch as long as the two it replaced (51 us vs 30 + 17 at
+      //    q = 1; step 7.35 vs 7.35 ms at q = 1, 11.4 vs 10.9 at q = 2, 37.8 vs 36.8 at q = 8).
       if (r + 1 < g1) update(r + 1, g1 - r - 1, r, r, cm_tri(g0, r + 1, g1 - r - 1, g0, r + 1 - g0), s, PK_TRAIL_ROW);
     }
   };
