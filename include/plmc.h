@@ -165,6 +165,9 @@ int plmc_w_diag_f64(const double *W, int64_t n_pad, int64_t ldw, int64_t strideW
  * Optional outputs (may be NULL): Kinv (n_pad x ldk upper tiles, batch stride strideK),
  * kinv_diag (q x n_pad: diagonal of K^-1, for leave-one-out, compute_loo :1108-1119).
  * partials: scratch of plmc_grad_scratch_bytes(n_pad, q) bytes.
+ * Opt-in (environment PLMC_BF16X3=1, fp32 entry point only): the W^T W products run on the bf16 matrix cores from a
+ * three-plane bf16 split of W (x = hi + mid + lo, six plane products, fp32 accumulate); the planes live behind the
+ * partials (plmc_grad_scratch_bytes grows by 6 q n_pad^2 bytes while the knob is set).  Off by default.
  */
 int plmc_kinv_grad_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW,
                        const float *alpha, const float *X, int n, int d, const float *ell,
@@ -258,8 +261,8 @@ int plmc_qr_small_f64(const double *A, int m, int n, int64_t lda, double *Q, int
  * plmc_potrf_* on the SAME device must not overlap in time from different host threads or caller streams (they would
  * share those events); different devices are independent.  The Python layer calls from one thread per process.
  * Dev knobs are environment variables read once per process (PLMC_HALF_TILES, PLMC_GRP, PLMC_KINV_ORDER,
- * PLMC_SERIAL); plmc_dev_reload_knobs() re-reads them (tests and bench.py change one and reload).  They change
- * schedules, never results.
+ * PLMC_SERIAL, PLMC_BULK_LDS); plmc_dev_reload_knobs() re-reads them (tests and bench.py change one and reload).  They change
+ * schedules, never results.  The one knob that changes arithmetic is PLMC_BF16X3 (off by default; plmc_kinv_grad_f32).
  * plmc_prof_mfma_rate: dense MFMA rate (TFLOP/s) of the current device measured with a bare instruction stream
  * (v_mfma_f32_16x16x4_f32 or _f64_16x16x4_f64, 4 waves per SIMD, no memory traffic); synchronous; `sink` = caller-owned
  * device scratch of at least 4 * CUs * 256 * sizeof(element) bytes.

@@ -50,6 +50,7 @@ struct Knobs {
   int grp;             // PLMC_GRP: fixed group size of the sweep (default 0 = 8)
   bool serial;         // PLMC_SERIAL: one stream, no look-ahead
   int bulk_lds;        // PLMC_BULK_LDS: extra dynamic LDS bytes per bulk workgroup (caps bulk occupancy); -1 = default by q
+  bool bf16x3;         // PLMC_BF16X3=1: fp32 K^-1 products on the bf16 matrix cores from three-plane split operands (opt-in)
   int kinv_order;      // PLMC_KINV_ORDER: tile order of the gradient kernel (0 XCD-dealt, 1 grid, 4 longest first, 5 = 4 + general epilogue)
 };
 const Knobs &knobs();

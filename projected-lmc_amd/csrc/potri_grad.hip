@@ -124,13 +124,16 @@ template <typename T, int DCAP> constexpr int KG_MIN_WAVES = sizeof(T) == 8 ? 2 
 
 // SPLINE (general epilogue only): the product-form spline kernel gets its own instantiation, so that its extra live
 // values do not raise the register pressure (and the scratch) of the stationary kernels' code.
-template <typename T, int DCAP, bool SPLINE = false>
-__global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad(int kind, const T *__restrict__ W, int64_t n_pad, int64_t ldw,
+// BF3 (fp32, opt-in): the W^T W product of the tile runs on the bf16 matrix cores from the three-plane split copy of W
+// (`Wp`: [latent][plane][n_pad][n_pad] bf16, written by k_split_w) -- tile_mainloop_bf3, gemm_core.hpp.
+template <typename T, int DCAP, bool SPLINE = false, bool BF3 = false>
+__global__ __launch_bounds__(NTHREADS, (BF3 ? (DCAP <= 16 ? 2 : 1) : KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad(int kind, const T *__restrict__ W, int64_t n_pad, int64_t ldw,
                                                          int64_t strideW, const T *__restrict__ alpha,
                                                          const T *__restrict__ X, int n, int d,
                                                          const T *__restrict__ ell, const T *__restrict__ oscale,
                                                          T *Kinv, int64_t ldk, int64_t strideK, T *kinv_diag,
-                                                         double *__restrict__ partials, int nlat, int plain) {
+                                                         double *__restrict__ partials, int nlat, int plain,
+                                                         const unsigned short *__restrict__ Wp) {
   const int m = (int)(n_pad / NB);
   int lat, ib, jb;
   if (plain >= 4) {                    // longest tiles first: jb ascending outermost, latent fastest
@@ -145,12 +148,20 @@ __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad
     jb = blockIdx.x; ib = blockIdx.y; lat = blockIdx.z;
     if (jb < ib) return;
   } else if (!xcd_tri_decode(blockIdx.x, m, nlat, lat, ib, jb)) return;   // XCD-dealt 8 x 8 super-tiles
-  __shared__ __align__(16) T smem[tile_smem_elems<T>()];
+  constexpr int SMEM_ELEMS = (BF3 && BF3_LDS_BYTES / (int)sizeof(T) > tile_smem_elems<T>()) ? BF3_LDS_BYTES / (int)sizeof(T) : tile_smem_elems<T>();
+  __shared__ __align__(16) T smem[SMEM_ELEMS];
   const T *Wl = W + (int64_t)lat * strideW + (int64_t)jb * NB * ldw;
   Acc<T> acc;
   acc.zero();
-  tile_mainloop<T, false, true>(acc, Wl + (int64_t)ib * NB, ldw, Wl + (int64_t)jb * NB, ldw, (int)(n_pad - (int64_t)jb * NB),
-                          smem);
+  if constexpr (BF3) {
+    static_assert(sizeof(T) == 4, "bf16x3 products stand in for fp32 products");
+    const unsigned short *Pl = Wp + (int64_t)lat * 3 * n_pad * n_pad + (int64_t)jb * NB * n_pad;
+    tile_mainloop_bf3(acc, Pl + (int64_t)ib * NB, Pl + (int64_t)jb * NB, n_pad, n_pad * n_pad, (int)(n_pad - (int64_t)jb * NB),
+                      reinterpret_cast<unsigned char *>(smem));
+  } else {
+    tile_mainloop<T, false, true>(acc, Wl + (int64_t)ib * NB, ldw, Wl + (int64_t)jb * NB, ldw, (int)(n_pad - (int64_t)jb * NB),
+                                  smem);
+  }
 
   // ---- epilogue: stage scaled inputs u = x / ell and alpha for the tile's rows and columns
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -507,6 +518,30 @@ int grad_tiles_impl(int kind, const T *A, int64_t n_pad, int64_t lda, int64_t st
   return launch_status(__func__);
 }
 
+// Three-plane bf16 split of the inverse factor for the BF3 gradient kernel: W (fp32, lower block triangle: block
+// (lb, cb) with cb <= lb) -> Wp[latent][plane][n_pad][n_pad].  grid (m, m, q), one 128 x 128 block per workgroup, eight
+// elements per thread and pass (two 16-byte loads, three 16-byte stores); HBM-bound.
+__global__ __launch_bounds__(NTHREADS) void k_split_w(const float *__restrict__ W, int64_t n_pad, int64_t ldw, int64_t strideW,
+                                                      unsigned short *__restrict__ Wp) {
+  const int cb = blockIdx.x, lb = blockIdx.y, lat = blockIdx.z;
+  if (cb > lb) return;
+  const float *src = W + (int64_t)lat * strideW + (int64_t)lb * NB * ldw + (int64_t)cb * NB;
+  unsigned short *dst = Wp + (int64_t)lat * 3 * n_pad * n_pad + (int64_t)lb * NB * n_pad + (int64_t)cb * NB;
+  const int64_t ps = n_pad * n_pad;
+  for (int c = threadIdx.x; c < NB * (NB / 8); c += NTHREADS) {
+    const int r = c >> 4, col = (c & 15) * 8;
+    const float4 v0 = *reinterpret_cast<const float4 *>(src + (int64_t)r * ldw + col);
+    const float4 v1 = *reinterpret_cast<const float4 *>(src + (int64_t)r * ldw + col + 4);
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    bf3_s16x8 h, m, l;
+    bf3_split8(x, h, m, l);
+    unsigned short *o = dst + (int64_t)r * n_pad + col;
+    *reinterpret_cast<bf3_s16x8 *>(o) = h;
+    *reinterpret_cast<bf3_s16x8 *>(o + ps) = m;
+    *reinterpret_cast<bf3_s16x8 *>(o + 2 * ps) = l;
+  }
+}
+
 template <typename T>
 int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, const T *alpha, const T *X, int n,
                    int d, const T *ell, const T *oscale, double *grad, T *Kinv, int64_t ldk, int64_t strideK,
@@ -527,18 +562,38 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
   const int plain = knobs().kinv_order;
   const dim3 grid = plain >= 4 ? dim3(q * (m * (m + 1) / 2)) : plain ? dim3(m, m, q) : dim3(xcd_tri_grid(m, q)), block(NTHREADS);
   double *part = reinterpret_cast<double *>(partials);
-#define PLMC_LAUNCH_KG(DC, ...)                                                                                     \
-  hipLaunchKernelGGL((k_kinv_grad<T, DC, ##__VA_ARGS__>), grid, block, 0, st, kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, \
-                     oscale, Kinv, ldk, strideK, kinv_diag, part, q, plain)
+  // opt-in (PLMC_BF16X3, fp32 only): split W into bf16 planes behind the partials, run the product on the bf16 cores
+  const unsigned short *Wp = nullptr;
+  bool bf3 = false;
+  if constexpr (sizeof(T) == 4) {
+    if (knobs().bf16x3) {
+      unsigned short *wp = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(partials) + (int64_t)m * m * q * GP * (int64_t)sizeof(double));
+      ProfScope ps(PK_WDIAG, st, 0.0, (double)q * n_pad * n_pad / 2 * (4 + 6));
+      hipLaunchKernelGGL(k_split_w, dim3(m, m, q), dim3(NTHREADS), 0, st, (const float *)W, n_pad, ldw, strideW, wp);
+      Wp = wp;
+      bf3 = true;
+    }
+  }
+#define PLMC_LAUNCH_KG2(DC, SP, B3)                                                                                  \
+  hipLaunchKernelGGL((k_kinv_grad<T, DC, SP, B3>), grid, block, 0, st, kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, \
+                     oscale, Kinv, ldk, strideK, kinv_diag, part, q, plain, Wp)
+#define PLMC_LAUNCH_KG(DC, SP)                                                                                      \
+  do {                                                                                                               \
+    if constexpr (sizeof(T) == 4) {                                                                                  \
+      if (bf3) { PLMC_LAUNCH_KG2(DC, SP, true); break; }                                                              \
+    }                                                                                                                \
+    PLMC_LAUNCH_KG2(DC, SP, false);                                                                                  \
+  } while (0)
   {
     const double np = (double)n_pad;
     ProfScope ps(PK_KINV_GRAD, st, q * np * np * np / 3.0, q * (np * np / 2) * sizeof(T));
-    if (d <= 4) PLMC_LAUNCH_KG(4);
-    else if (d <= 8) PLMC_LAUNCH_KG(8);
-    else if (d <= 16) { if (kind == K_SPLINE) PLMC_LAUNCH_KG(16, true); else PLMC_LAUNCH_KG(16); }
-    else { if (kind == K_SPLINE) PLMC_LAUNCH_KG(32, true); else PLMC_LAUNCH_KG(32); }
+    if (d <= 4) PLMC_LAUNCH_KG(4, false);
+    else if (d <= 8) PLMC_LAUNCH_KG(8, false);
+    else if (d <= 16) { if (kind == K_SPLINE) PLMC_LAUNCH_KG(16, true); else PLMC_LAUNCH_KG(16, false); }
+    else { if (kind == K_SPLINE) PLMC_LAUNCH_KG(32, true); else PLMC_LAUNCH_KG(32, false); }
   }
 #undef PLMC_LAUNCH_KG
+#undef PLMC_LAUNCH_KG2
   {
     ProfScope ps(PK_REDUCE, st, 0.0, (double)plmc_grad_scratch_bytes(n_pad, q) / 2);
     hipLaunchKernelGGL(k_reduce_grad<T>, dim3(q), dim3(RED_NT), 0, st, part, m, d, ell, grad);
@@ -561,7 +616,8 @@ int plmc_grad_tiles_f64(int kind, const double *A, int64_t n_pad, int64_t lda, i
 }
 int64_t plmc_grad_scratch_bytes(int64_t n_pad, int q) {
   int64_t m = n_pad / plmc::NB;
-  return m * m * (int64_t)q * plmc::GP * (int64_t)sizeof(double);
+  const int64_t planes = plmc::knobs().bf16x3 ? (int64_t)q * 3 * n_pad * n_pad * 2 : 0;   // bf16 planes of W (opt-in, fp32)
+  return m * m * (int64_t)q * plmc::GP * (int64_t)sizeof(double) + planes;
 }
 int plmc_kinv_grad_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW, const float *alpha,
                        const float *X, int n, int d, const float *ell, const float *oscale, double *grad,

@@ -86,6 +86,35 @@ def _multi_group_body(eng, n, d, q):
     assert torch.allclose(y_d.grad.cpu(), ref[4], rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("n,d,q", [(1000, 8, 2), (2300, 12, 3)])
+def test_bf16x3_gradient_kernel_matches_fp32_path(eng, n, d, q):
+    """Opt-in PLMC_BF16X3=1: the W^T W products of the gradient kernel run on the bf16 matrix cores from three-plane
+    split operands.  Same fp32 tolerance against the fp64 oracle as the plain path, and within 2e-5 (of the largest
+    magnitude) of the plain fp32 path itself."""
+    from projectedlmc import _hip
+    X, y, ell, noise, osc = _problem(n, d, q, seed=n + 1)
+    ref = gm.exact_latent_log_prob_analytic("matern", X, ell, noise, y, None, 2.5)
+    dev = torch.device("cuda:0")
+    f = lambda t: t.to(dev, torch.float32)
+
+    def run():
+        ell_d, nz_d, y_d = f(ell).requires_grad_(), f(noise).requires_grad_(), f(y).requires_grad_()
+        lp = eng.exact_latent_log_prob("matern52", f(X), ell_d, None, nz_d, y_d)
+        lp.sum().backward()
+        torch.cuda.synchronize()
+        return [t.detach().cpu().double() for t in (lp, ell_d.grad, nz_d.grad, y_d.grad)]
+
+    plain = run()
+    eng.free_workspaces()                                   # the planes live behind the gradient partials: new workspace
+    with _hip.knob("PLMC_BF16X3", "1"):
+        split = run()
+        eng.free_workspaces()
+    for got, base, want in zip(split[1:3], plain[1:3], (ref[1], ref[2])):
+        assert (got - want).abs().max() / want.abs().max() < 2e-3
+        assert (got - base).abs().max() / base.abs().max() < 2e-5, (got, base)
+    assert torch.equal(split[0], plain[0]) and torch.equal(split[3], plain[3])    # log-prob and d/dy do not use K^-1
+
+
 @pytest.mark.parametrize("kind", ["rbf", "matern52"])
 def test_logprob_and_grad_fp32(eng, kind):
     """fp32 tolerance: log-prob within 1e-4 relative of the fp64 oracle (BASELINE.json target),
