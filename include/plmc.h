@@ -262,7 +262,8 @@ int plmc_qr_small_f64(const double *A, int m, int n, int64_t lda, double *Q, int
  * share those events); different devices are independent.  The Python layer calls from one thread per process.
  * Dev knobs are environment variables read once per process (PLMC_HALF_TILES, PLMC_GRP, PLMC_KINV_ORDER,
  * PLMC_SERIAL, PLMC_BULK_LDS); plmc_dev_reload_knobs() re-reads them (tests and bench.py change one and reload).  They change
- * schedules, never results.  The one knob that changes arithmetic is PLMC_BF16X3 (off by default; plmc_kinv_grad_f32).
+ * schedules, never results.  The one knob that changes arithmetic is PLMC_BF16X3 (off by default; plmc_kinv_grad_f32, and the depth-(128 G) tail / head
+ * updates inside plmc_potrf_f32, whose Vd scratch -- plmc_vd_blocks -- then also holds a rolling bf16 plane buffer).
  * plmc_prof_mfma_rate: dense MFMA rate (TFLOP/s) of the current device measured with a bare instruction stream
  * (v_mfma_f32_16x16x4_f32 or _f64_16x16x4_f64, 4 waves per SIMD, no memory traffic); synchronous; `sink` = caller-owned
  * device scratch of at least 4 * CUs * 256 * sizeof(element) bytes.

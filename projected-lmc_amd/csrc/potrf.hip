@@ -141,6 +141,47 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
   else tile_writeback<T, WB_SUB, MT>(acc, C, ldc, smem);               // C -= P^T P
 }
 
+// Opt-in (PLMC_BF16X3, fp32): the bulk trailing updates (tail, head rows; full tiles) with their depth-(128 G) products on
+// the bf16 matrix cores.  The operands are the panel rows of the current group, which k_gpanel_copy / k_vtrans also write
+// as three bf16 planes (x = hi + mid + lo) into a rolling two-group buffer `Pl` ([buffer][plane][128 GMAX rows][lda],
+// same column coordinates as the factor buffer); tile decoding, depth rules and the write-back are those of update_tile.
+template <int ROLE>
+__global__ __launch_bounds__(NTHREADS, 2) void k_update_bf3(float *A, int64_t lda, int64_t strideA, int ib0, int r_lo, int r_hi,
+                                                            ColMap<float> cm, int skip_ib, int skip_jb, const unsigned short *__restrict__ Pl,
+                                                            int64_t pl_lat_stride, int64_t plane_stride, int64_t wcol0) {
+  if (ROLE == 3) __builtin_amdgcn_s_setprio(2);
+  extern __shared__ __align__(16) unsigned char dyn_pad[];             // occupancy cap of the bulk launches (few latents)
+  __shared__ __align__(16) unsigned char lds[BF3_LDS_BYTES];
+  const int bx = blockIdx.x, ib = ib0 + (int)blockIdx.y, lat = blockIdx.z;
+  int kr0 = r_lo * NB, depth = (r_hi - r_lo + 1) * NB;
+  bool first = false;
+  float *Al = A + (int64_t)lat * strideA;
+  float *Cb = Al;
+  int64_t ldc = lda, col0, colp;                                       // colp: column of the B operand in the plane buffer
+  if (bx < cm.nU) {
+    const int jb = cm.u0 + bx;
+    if (jb < ib || (ib < skip_ib && jb < skip_jb)) return;
+    col0 = colp = (int64_t)jb * NB;
+  } else if (bx < cm.nU + cm.Taug) {
+    col0 = colp = cm.n_pad + (int64_t)(bx - cm.nU) * NB;
+  } else {
+    const int cb = cm.w0 + bx - cm.nU - cm.Taug;
+    Cb = cm.W + (int64_t)lat * cm.strideW;
+    ldc = cm.ldw;
+    col0 = (int64_t)cb * NB;
+    colp = wcol0 + col0;
+    if (cb >= r_lo) { first = true; kr0 = cb * NB; depth = (r_hi - cb + 1) * NB; }
+  }
+  Acc<float> acc;
+  acc.zero();
+  const unsigned short *Pr = Pl + (int64_t)lat * pl_lat_stride + (int64_t)(kr0 - r_lo * NB) * lda;
+  tile_mainloop_bf3(acc, Pr + (int64_t)ib * NB, Pr + colp, lda, plane_stride, depth, lds);
+  float *C = Cb + (int64_t)ib * NB * ldc + col0;
+  if (first) tile_writeback<float, WB_STORE_NEG>(acc, C, ldc, reinterpret_cast<float *>(lds));
+  else tile_writeback<float, WB_SUB>(acc, C, ldc, reinterpret_cast<float *>(lds));
+  if (dyn_pad[0] == 123 && threadIdx.x == 99999) A[0] = 0.f;          // keeps the dynamic LDS request alive
+}
+
 // Group panel: U^-T applied to the whole block row of the group as products with Vgg = Ugg^-1 (upper, K-major, leading
 // dimension ldv).  One workgroup per (128-column strip t of the column map, block row i of the group):
 //     Pb[i][t] = sum_{k <= i} Vgg[k][i]^T A[k][strip t]         (depth 128 (i + 1))
@@ -196,19 +237,41 @@ __global__ __launch_bounds__(NTHREADS, (sizeof(T) == 8 || HEAD ? 2 : 4)) void k_
 // Panel buffer -> factor buffer (block row g0 + i, column strip t of the column map).  grid (tiles, G, q); HBM-bound.
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_gpanel_copy(T *A, int64_t lda, int64_t strideA, int g0, ColMap<T> cm, const T *__restrict__ Pb,
-                                                          int64_t ldp, int64_t strideP) {
+                                                          int64_t ldp, int64_t strideP, unsigned short *__restrict__ Pl, int64_t pl_lat_stride,
+                                                          int64_t plane_stride, int64_t wcol0) {
   using vec_t = typename Traits<T>::vec_t;
   constexpr int EPV = Traits<T>::EPV, CPR = NB / EPV;
   const int lat = blockIdx.z, t = blockIdx.x, i = blockIdx.y;
   T *D;
-  int64_t ldd = lda;
-  if (t < cm.nU) D = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + (int64_t)(cm.u0 + t) * NB;
-  else if (t < cm.nU + cm.Taug) D = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + cm.n_pad + (int64_t)(t - cm.nU) * NB;
+  int64_t ldd = lda, colp;                                 // colp: the strip's column in factor-buffer coordinates
+  if (t < cm.nU) { colp = (int64_t)(cm.u0 + t) * NB; D = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + colp; }
+  else if (t < cm.nU + cm.Taug) { colp = cm.n_pad + (int64_t)(t - cm.nU) * NB; D = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + colp; }
   else {
     ldd = cm.ldw;
+    colp = wcol0 + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
     D = cm.W + (int64_t)lat * cm.strideW + (int64_t)(g0 + i) * NB * ldd + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
   }
   const T *S = Pb + (int64_t)lat * strideP + (int64_t)i * NB * ldp + (int64_t)t * NB;
+  if constexpr (sizeof(T) == 4) {
+    if (Pl) {                                              // PLMC_BF16X3: the finished rows also as three bf16 planes
+      unsigned short *P0 = Pl + (int64_t)lat * pl_lat_stride + (int64_t)i * NB * lda + colp;
+      for (int c = threadIdx.x; c < NB * (NB / 8); c += NTHREADS) {
+        const int r = c >> 4, col = (c & 15) * 8;
+        const float4 v0 = *reinterpret_cast<const float4 *>(S + (int64_t)r * ldp + col);
+        const float4 v1 = *reinterpret_cast<const float4 *>(S + (int64_t)r * ldp + col + 4);
+        *reinterpret_cast<float4 *>(D + (int64_t)r * ldd + col) = v0;
+        *reinterpret_cast<float4 *>(D + (int64_t)r * ldd + col + 4) = v1;
+        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        bf3_s16x8 h, m, l;
+        bf3_split8(x, h, m, l);
+        unsigned short *o = P0 + (int64_t)r * lda + col;
+        *reinterpret_cast<bf3_s16x8 *>(o) = h;
+        *reinterpret_cast<bf3_s16x8 *>(o + plane_stride) = m;
+        *reinterpret_cast<bf3_s16x8 *>(o + 2 * plane_stride) = l;
+      }
+      return;
+    }
+  }
   for (int c = threadIdx.x; c < NB * CPR; c += NTHREADS) {
     const int r = c / CPR, col = (c % CPR) * EPV;
     *reinterpret_cast<vec_t *>(D + (int64_t)r * ldd + col) = *reinterpret_cast<const vec_t *>(S + (int64_t)r * ldp + col);
@@ -218,9 +281,10 @@ __global__ __launch_bounds__(NTHREADS) void k_gpanel_copy(T *A, int64_t lda, int
 // Transpose of the group's inverse triangle: Vg[k][i] = Wg[i][k]^T for block pairs k <= i < G (Vg = Ugg^-1, upper,
 // K-major for the tile engine) and, when the inverse factor is wanted, the copy of Wg[i][k] into the factor buffer's
 // W columns (block row g0 + i, block column g0 + k).  grid (G (G + 1) / 2, q), 32 x 32 sub-tiles through LDS.
-template <typename T>
+template <typename T, bool PLANES = false>
 __global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, int64_t strideG, T *__restrict__ Vg, int G, T *Wout,
-                                                     int64_t ldw, int64_t strideW) {
+                                                     int64_t ldw, int64_t strideW, unsigned short *__restrict__ Pl, int64_t pl_lat_stride,
+                                                     int64_t plane_stride, int64_t pl_ld, int64_t pl_col0) {
   __builtin_amdgcn_s_setprio(3);
   __shared__ T tile[32][33];
   const int lat = blockIdx.y;
@@ -229,6 +293,8 @@ __global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, i
   const T *src = Wg + (int64_t)lat * strideG + (int64_t)i * NB * LDG + (int64_t)k * NB;
   T *dst = Vg + (int64_t)lat * strideG + (int64_t)k * NB * LDG + (int64_t)i * NB;
   T *wo = Wout ? Wout + (int64_t)lat * strideW + (int64_t)i * NB * ldw + (int64_t)k * NB : nullptr;
+  // PLMC_BF16X3 (fp32): the triangle's rows also as three bf16 planes (row i NB + r, column pl_col0 + k NB + c)
+  unsigned short *po = (PLANES && Pl) ? Pl + (int64_t)lat * pl_lat_stride + (int64_t)i * NB * pl_ld + pl_col0 + (int64_t)k * NB : nullptr;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
   for (int bi = 0; bi < NB; bi += 32)
     for (int bk = 0; bk < NB; bk += 32) {
@@ -237,6 +303,18 @@ __global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, i
         const T v = src[(int64_t)(bi + ty + r) * LDG + bk + tx];
         tile[ty + r][tx] = v;
         if (wo) wo[(int64_t)(bi + ty + r) * ldw + bk + tx] = v;
+        if constexpr (PLANES && sizeof(T) == 4) {
+          if (po) {
+            const __bf16 a = (__bf16)v;
+            const float r1 = v - (float)a;
+            const __bf16 b = (__bf16)r1;
+            const __bf16 c = (__bf16)(r1 - (float)b);
+            unsigned short *o = po + (int64_t)(bi + ty + r) * pl_ld + bk + tx;
+            o[0] = __builtin_bit_cast(unsigned short, a);
+            o[plane_stride] = __builtin_bit_cast(unsigned short, b);
+            o[2 * plane_stride] = __builtin_bit_cast(unsigned short, c);
+          }
+        }
       }
       __syncthreads();
 #pragma unroll
@@ -404,6 +482,15 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   T *const Ph = Wg + 3 * (int64_t)GMAX * NB * LDG;                      // panel buffer of the head columns (ld LDG)
   T *const Pbulk = Ph + (int64_t)GMAX * NB * LDG;                       // panel buffer of the other columns (ld lda)
   T *const Kd = Vd + strideV - (int64_t)m * NB * NB;                    // diagonal tiles of the accumulated K^-1: last m blocks
+  // PLMC_BF16X3 (fp32, opt-in): rolling two-group buffer of the panel rows as three bf16 planes, behind the bulk panel buffer
+  const bool bf3 = sizeof(T) == 4 && knobs().bf16x3;
+  const int64_t pl_plane = (int64_t)GMAX * NB * lda;                    // elements between planes
+  unsigned short *const Pl0 = bf3 ? reinterpret_cast<unsigned short *>(Pbulk + (int64_t)GMAX * NB * lda) : nullptr;
+  const int64_t pl_lat = strideV * (int64_t)(sizeof(T) / 2);            // latent stride in 16-bit elements
+  const int grp_rows = (knobs().grp > 0 && knobs().grp < GMAX) ? knobs().grp : GMAX;   // block rows per group (as below)
+  auto planes = [&](int g0) -> unsigned short * {                       // buffer of the group that starts at block row g0
+    return bf3 ? Pl0 + (int64_t)((g0 / grp_rows) & 1) * 3 * pl_plane : nullptr;
+  };
   const bool kacc_on = with_inverse == 2;
   T *const WA = with_inverse ? A + wcol0 : (T *)nullptr;                // inverse-factor columns of the factor buffer
 
@@ -471,6 +558,16 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     const bool half = cls != PK_TRAIL && (double)Cn * nrows * q <= hthr;
     const dim3 grid(Cn, half ? 2 * nrows : nrows, q);
     const unsigned dyn = (cls == PK_TRAIL || (cls == PK_TRAIL_HEAD && !crit)) ? bulk_lds : 0u;
+    if constexpr (sizeof(T) == 4) {
+      if (bf3 && !half && (cls == PK_TRAIL || (cls == PK_TRAIL_HEAD && !crit))) {
+        const unsigned short *pl = planes(r_lo);
+        if (cls == PK_TRAIL)
+          hipLaunchKernelGGL((k_update_bf3<0>), grid, dim3(NTHREADS), dyn, s, A, lda, strideA, ib0, r_lo, r_hi, cm, skip_ib, skip_jb, pl, pl_lat, pl_plane, wcol0);
+        else
+          hipLaunchKernelGGL((k_update_bf3<3>), grid, dim3(NTHREADS), dyn, s, A, lda, strideA, ib0, r_lo, r_hi, cm, skip_ib, skip_jb, pl, pl_lat, pl_plane, wcol0);
+        return;
+      }
+    }
 #define PLMC_UPD(ROLE, MT) \
   hipLaunchKernelGGL((k_update<T, ROLE, MT>), grid, dim3(NTHREADS), dyn, s, A, lda, strideA, ib0, r_lo, r_hi, cm, skip_ib, skip_jb)
     if (cls == PK_TRAIL_ROW) { if (half && q <= 2 && r_hi == r_lo) PLMC_UPD(4, 2); else if (half) PLMC_UPD(1, 2); else PLMC_UPD(1, 4); }
@@ -495,7 +592,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
         hipLaunchKernelGGL((k_gpanel_rows<T, 0>), dim3(nt, (G + 1) / 2, q), dim3(NTHREADS), bulk_lds, s, (const T *)A, lda, strideA, g0, G, cm, Vg,
                            (int64_t)LDG, strideV, Pb, ldp, strideV);
     }
-    hipLaunchKernelGGL((k_gpanel_copy<T>), dim3(nt, G, q), dim3(NTHREADS), 0, s, A, lda, strideA, g0, cm, (const T *)Pb, ldp, strideV);
+    hipLaunchKernelGGL((k_gpanel_copy<T>), dim3(nt, G, q), dim3(NTHREADS), 0, s, A, lda, strideA, g0, cm, (const T *)Pb, ldp, strideV,
+                       planes(g0), pl_lat, pl_plane, wcol0);
   };
 
   // whole-sweep bracket on the caller's stream (the per-kernel records of overlapped kernels add up to
@@ -549,8 +647,12 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   auto vtrans = [&](int gi, hipStream_t s) {
     const int g0 = G0(gi), G = G0(gi + 1) - g0;
     T *wo = WA ? WA + (int64_t)g0 * NB * lda + (int64_t)g0 * NB : (T *)nullptr;
-    hipLaunchKernelGGL(k_vtrans<T>, dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)Wg, strideV, Vg2[gi & 1], G, wo, lda,
-                       strideA);
+    if (bf3 && WA)
+      hipLaunchKernelGGL((k_vtrans<T, true>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)Wg, strideV, Vg2[gi & 1], G, wo, lda,
+                         strideA, planes(g0), pl_lat, pl_plane, lda, wcol0 + (int64_t)g0 * NB);
+    else
+      hipLaunchKernelGGL((k_vtrans<T, false>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)Wg, strideV, Vg2[gi & 1], G, wo, lda,
+                         strideA, (unsigned short *)nullptr, pl_lat, pl_plane, lda, wcol0 + (int64_t)g0 * NB);
   };
 
   auto kacc = [&](int gi, hipStream_t s) {
@@ -668,7 +770,9 @@ int w_diag_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, T *kinv
 
 extern "C" {
 int64_t plmc_vd_blocks(int64_t n_pad, int64_t lda) {
-  return 2 * (n_pad / plmc::NB) + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ((lda + plmc::NB - 1) / plmc::NB);
+  // PLMC_BF16X3: + the rolling plane buffer, 2 groups x 3 planes x (128 GMAX) x lda 16-bit elements = 3 GMAX lda / 128 fp32 blocks
+  const int64_t planes = plmc::knobs().bf16x3 ? 3 * plmc::GMAX * ((lda + plmc::NB - 1) / plmc::NB) : 0;
+  return 2 * (n_pad / plmc::NB) + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ((lda + plmc::NB - 1) / plmc::NB) + planes;
 }
 int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet,
                    int *info, int with_inverse, int q, void *stream) {

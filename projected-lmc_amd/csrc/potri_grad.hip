@@ -568,7 +568,7 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
   if constexpr (sizeof(T) == 4) {
     if (knobs().bf16x3) {
       unsigned short *wp = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(partials) + (int64_t)m * m * q * GP * (int64_t)sizeof(double));
-      ProfScope ps(PK_WDIAG, st, 0.0, (double)q * n_pad * n_pad / 2 * (4 + 6));
+      ProfScope ps(PK_SPLIT, st, 0.0, (double)q * n_pad * n_pad / 2 * (4 + 6));
       hipLaunchKernelGGL(k_split_w, dim3(m, m, q), dim3(NTHREADS), 0, st, (const float *)W, n_pad, ldw, strideW, wp);
       Wp = wp;
       bf3 = true;

@@ -86,11 +86,12 @@ def _multi_group_body(eng, n, d, q):
     assert torch.allclose(y_d.grad.cpu(), ref[4], rtol=1e-7, atol=1e-9)
 
 
-@pytest.mark.parametrize("n,d,q", [(1000, 8, 2), (2300, 12, 3)])
-def test_bf16x3_gradient_kernel_matches_fp32_path(eng, n, d, q):
-    """Opt-in PLMC_BF16X3=1: the W^T W products of the gradient kernel run on the bf16 matrix cores from three-plane
-    split operands.  Same fp32 tolerance against the fp64 oracle as the plain path, and within 2e-5 (of the largest
-    magnitude) of the plain fp32 path itself."""
+@pytest.mark.parametrize("n,d,q", [(1000, 8, 2), (2300, 12, 3), (4200, 5, 2)])
+def test_bf16x3_option_matches_fp32_path(eng, n, d, q):
+    """Opt-in PLMC_BF16X3=1: the depth-1024 trailing updates of the sweep (from three groups of block rows on) and the
+    W^T W products of the gradient kernel run on the bf16 matrix cores from three-plane split operands (six plane
+    products, fp32 accumulate).  Same fp32 tolerance against the fp64 oracle as the plain path, and within 2e-5 (of
+    the largest magnitude) of the plain fp32 path itself."""
     from projectedlmc import _hip
     X, y, ell, noise, osc = _problem(n, d, q, seed=n + 1)
     ref = gm.exact_latent_log_prob_analytic("matern", X, ell, noise, y, None, 2.5)
@@ -112,7 +113,9 @@ def test_bf16x3_gradient_kernel_matches_fp32_path(eng, n, d, q):
     for got, base, want in zip(split[1:3], plain[1:3], (ref[1], ref[2])):
         assert (got - want).abs().max() / want.abs().max() < 2e-3
         assert (got - base).abs().max() / base.abs().max() < 2e-5, (got, base)
-    assert torch.equal(split[0], plain[0]) and torch.equal(split[3], plain[3])    # log-prob and d/dy do not use K^-1
+    for got, base, want in ((split[0], plain[0], ref[0]), (split[3], plain[3], ref[4])):
+        assert (got - want).abs().max() / want.abs().max() < 1e-4
+        assert (got - base).abs().max() / base.abs().max() < 2e-5, (got, base)
 
 
 @pytest.mark.parametrize("kind", ["rbf", "matern52"])
