@@ -555,11 +555,15 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     const double bytes = (2.0 * (tilesU + nr * (cm.Taug + cm.nW)) - nr * nfirst) * nb * nb * esz;
     ProfScope ps(cls, s, q * flops, q * bytes);
     // launches with few tiles run on 64-row half tiles: twice the workgroups
-    const bool half = cls != PK_TRAIL && (double)Cn * nrows * q <= hthr;
+    // PLMC_BF16X3: which engine a tile goes through must not depend on the schedule (bit-identical results with and
+    // without the look-ahead): every tail / head tile takes the bf16x3 engine on full tiles, the next group's triangle
+    // (U1; `crit`) and the chain stay on the fp32 MFMAs
+    const bool use_bf3 = bf3 && (cls == PK_TRAIL || (cls == PK_TRAIL_HEAD && !crit));
+    const bool half = !use_bf3 && cls != PK_TRAIL && (double)Cn * nrows * q <= hthr;
     const dim3 grid(Cn, half ? 2 * nrows : nrows, q);
     const unsigned dyn = (cls == PK_TRAIL || (cls == PK_TRAIL_HEAD && !crit)) ? bulk_lds : 0u;
     if constexpr (sizeof(T) == 4) {
-      if (bf3 && !half && (cls == PK_TRAIL || (cls == PK_TRAIL_HEAD && !crit))) {
+      if (use_bf3) {
         const unsigned short *pl = planes(r_lo);
         if (cls == PK_TRAIL)
           hipLaunchKernelGGL((k_update_bf3<0>), grid, dim3(NTHREADS), dyn, s, A, lda, strideA, ib0, r_lo, r_hi, cm, skip_ib, skip_jb, pl, pl_lat, pl_plane, wcol0);
@@ -680,7 +684,13 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       chain(gi, st);
       vtrans(gi, st);
       gpanel(g0, g1 - g0, cm_buf(g1, m - g1, Taug, 0, g0), Vg2[gi & 1], st, 0);
-      update(g1, m - g1, g0, g1 - 1, cm_buf(g1, m - g1, Taug, 0, g1), st, PK_TRAIL);
+      if (bf3) {             // as under the look-ahead: the next group's triangle on the fp32 MFMAs, the rest on bf16x3
+        const int g2 = G0(gi + 2);
+        update(g1, m - g1, g0, g1 - 1, cm_buf(g1, m - g1, Taug, 0, g1), st, PK_TRAIL, g2, g2);
+        update(g1, g2 - g1, g0, g1 - 1, cm_buf(g1, g2 - g1, 0, 0, 0), st, PK_TRAIL_HEAD, 0, 0, true);
+      } else {
+        update(g1, m - g1, g0, g1 - 1, cm_buf(g1, m - g1, Taug, 0, g1), st, PK_TRAIL);
+      }
       kacc(gi, st);
     }
     return finish();

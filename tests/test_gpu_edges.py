@@ -179,15 +179,26 @@ def test_sarcos_scale_single_latent_fp32(eng):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("n,q,dtype", [(8192, 8, torch.float32), (8192, 2, torch.float32), (4096, 4, torch.float64)],
-                         ids=["metric-f32-q8-wsplit", "f32-q2-two-streams", "f64-q4"])
-def test_sweep_is_deterministic_and_schedule_independent(eng, n, q, dtype):
+@pytest.mark.parametrize("n,q,dtype,bf3", [(8192, 8, torch.float32, False), (8192, 2, torch.float32, False),
+                                             (4096, 4, torch.float64, False), (8192, 4, torch.float32, True)],
+                         ids=["metric-f32-q8-wsplit", "f32-q2-two-streams", "f64-q4", "f32-q4-bf16x3-option"])
+def test_sweep_is_deterministic_and_schedule_independent(eng, n, q, dtype, bf3):
     """The look-ahead runs the chain, the head and the tail updates of the sweep on two or three streams (three with
     q >= 4: the inverse-factor columns get their own chain); every tile still receives its updates in a fixed order, so
     (a) repeated factorisations must agree bit for bit over the WHOLE factor buffer (U, augmented column, W), and
     (b) they must agree bit for bit with the one-stream schedule (PLMC_SERIAL=1).  A race between the streams, or a
     store-data hazard in the tile write-back ("Write-back hazard": round 1's "wrong factors under the
-    look-ahead" was exactly that and showed up here as thousands of differing tiles), fails this test."""
+    look-ahead" was exactly that and showed up here as thousands of differing tiles), fails this test.
+    Also with the opt-in PLMC_BF16X3 arithmetic (which tiles take the bf16x3 engine does not depend on the schedule)."""
+    import os
+    import contextlib
+    from projectedlmc import _hip
+    with (_hip.knob("PLMC_BF16X3", "1") if bf3 else contextlib.nullcontext()):
+        _schedule_independence_body(eng, n, q, dtype)
+        eng.free_workspaces()
+
+
+def _schedule_independence_body(eng, n, q, dtype):
     import os
     d = 8
     g = torch.Generator().manual_seed(5)

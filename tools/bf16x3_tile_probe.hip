@@ -117,10 +117,38 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_bf3_tiles(const unsigned short 
     sstore();
     __syncthreads();
     if (s + 1 < nst) gload(s + 1);
+    if constexpr (NPROD == 66) {
+      // six products with every fragment read once per role: B.hi stays live, A planes walk lo -> mid -> hi
+      bf16x8 a[4], b[4], bh[4];
+      auto mm = [&](bf16x8 (&x)[4], bf16x8 (&y)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc.v[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[mt], y[nt], acc.v[mt][nt], 0, 0, 0);
+      };
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bh[i] = frag(3 + 0, wn * 4 + i);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = frag(2, wm * 4 + i);      // A.lo
+      mm(a, bh);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = frag(1, wm * 4 + i);      // A.mid
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[i] = frag(3 + 1, wn * 4 + i);  // B.mid
+      mm(a, b);
+      mm(a, bh);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = frag(0, wm * 4 + i);      // A.hi
+      mm(a, b);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[i] = frag(3 + 2, wn * 4 + i);  // B.lo
+      mm(a, b);
+      mm(a, bh);
+    } else {
     // plane products, small terms first: (A plane, B plane)
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-    for (int pr = 6 - NPROD; pr < 6; ++pr) {
+    for (int pr = 6 - (NPROD > 6 ? 6 : NPROD); pr < 6; ++pr) {
       bf16x8 a[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = frag(PA[pr], wm * 4 + i);
@@ -130,6 +158,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_bf3_tiles(const unsigned short 
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc.v[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc.v[mt][nt], 0, 0, 0);
+    }
     }
     __syncthreads();
   }
@@ -197,6 +226,7 @@ int main() {
   };
   if (time_it("fp32 engine (16x16x4 f32)", [&]() { hipLaunchKernelGGL(k_f32_tiles, dim3(TPR * TPR), dim3(NTHREADS), 0, 0, M0, ld, K, TPR); })) return 1;
   if (time_it("bf16x3, 6 plane products", [&]() { hipLaunchKernelGGL((k_bf3_tiles<6>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
+  if (time_it("bf16x3, 6 products, fragments reused", [&]() { hipLaunchKernelGGL((k_bf3_tiles<66>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
   if (time_it("bf16x3, 3 products (speed only)", [&]() { hipLaunchKernelGGL((k_bf3_tiles<3>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
   if (time_it("bf16, 1 product (speed only)", [&]() { hipLaunchKernelGGL((k_bf3_tiles<1>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
   return 0;
