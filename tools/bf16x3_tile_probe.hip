@@ -58,6 +58,7 @@ constexpr int PLANE_LDS = BKH * ROWB;       // 8 KB per plane and operand
 // together (k = 8g + 4j + q for lane groups g = 0, 1) are eight consecutive LDS rows -> eight different 32-byte slots
 __device__ __forceinline__ int lds_row(int k) { return (k & 19) | ((k >> 1) & 4) | ((k << 1) & 8); }
 
+// (a 3-waves-per-SIMD register bound spills 220 bytes per lane: 48 staging + 64 accumulator + 48 fragment registers)
 template <int NPROD>
 __global__ __launch_bounds__(NTHREADS, 1) void k_bf3_tiles(const unsigned short *__restrict__ P, int64_t ldp, int64_t plane_stride, float *M,
                                                            int64_t ld, int K, int tiles_per_row) {
