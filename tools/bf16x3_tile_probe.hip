@@ -59,7 +59,7 @@ constexpr int PLANE_LDS = BKH * ROWB;       // 8 KB per plane and operand
 __device__ __forceinline__ int lds_row(int k) { return (k & 19) | ((k >> 1) & 4) | ((k << 1) & 8); }
 
 // (a 3-waves-per-SIMD register bound spills 220 bytes per lane: 48 staging + 64 accumulator + 48 fragment registers)
-template <int NPROD>
+template <int NPROD, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS, 1) void k_bf3_tiles(const unsigned short *__restrict__ P, int64_t ldp, int64_t plane_stride, float *M,
                                                            int64_t ld, int K, int tiles_per_row) {
   __shared__ __align__(16) unsigned char lds[6 * PLANE_LDS];              // [A hi, mid, lo | B hi, mid, lo][32 rows][256 B]
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_bf3_tiles(const unsigned short 
   const int nst = K / BKH;
   gload(0);
   for (int s = 0; s < nst; ++s) {
-    sstore();
+    if (!(ABL & 2) || s == 0) sstore();
     __syncthreads();
-    if (s + 1 < nst) gload(s + 1);
+    if (!(ABL & 1) && s + 1 < nst) gload(s + 1);
     if constexpr (NPROD == 66) {
       // six products with every fragment read once per role: B.hi stays live, A planes walk lo -> mid -> hi
       bf16x8 a[4], b[4], bh[4];
@@ -228,6 +228,8 @@ int main() {
   if (time_it("fp32 engine (16x16x4 f32)", [&]() { hipLaunchKernelGGL(k_f32_tiles, dim3(TPR * TPR), dim3(NTHREADS), 0, 0, M0, ld, K, TPR); })) return 1;
   if (time_it("bf16x3, 6 plane products", [&]() { hipLaunchKernelGGL((k_bf3_tiles<6>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
   if (time_it("bf16x3, 6 products, fragments reused", [&]() { hipLaunchKernelGGL((k_bf3_tiles<66>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
+  if (time_it("  ablation: no global loads in the loop", [&]() { hipLaunchKernelGGL((k_bf3_tiles<66, 1>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
+  if (time_it("  ablation: no loads, no LDS stores", [&]() { hipLaunchKernelGGL((k_bf3_tiles<66, 3>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
   if (time_it("bf16x3, 3 products (speed only)", [&]() { hipLaunchKernelGGL((k_bf3_tiles<3>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
   if (time_it("bf16, 1 product (speed only)", [&]() { hipLaunchKernelGGL((k_bf3_tiles<1>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
   return 0;
