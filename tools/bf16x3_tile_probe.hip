@@ -166,6 +166,111 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_bf3_tiles(const unsigned short 
   tile_writeback<float, WB_SUB>(acc, M + ((int64_t)K + (int64_t)ib * NB) * ld + (int64_t)jb * NB, ld, reinterpret_cast<float *>(lds));
 }
 
+// Second form: 512 threads = 8 waves (2 x 4, 64 x 32 per wave), TWO LDS stages (96 KB, one workgroup per CU), one barrier
+// per stage: the stores of stage s + 1 go to the other buffer at the top of iteration s and overlap the MFMAs of the
+// other waves; 24 staging + 32 accumulator registers per lane.  Epilogue: the whole tile through LDS, coalesced
+// read-modify-write with 16-byte accesses.
+__global__ __launch_bounds__(512, 2) void k_bf3_tiles8(const unsigned short *__restrict__ P, int64_t ldp, int64_t plane_stride, float *M,
+                                                       int64_t ld, int K, int tiles_per_row) {
+  extern __shared__ __align__(16) unsigned char lds[];                    // 2 x 6 x PLANE_LDS
+  const int t = blockIdx.x, ib = t / tiles_per_row, jb = t % tiles_per_row;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+  const int lrow = tid >> 4, lch = tid & 15;                              // one 16-byte chunk per plane and operand
+  const unsigned short *gA = P + (int64_t)lrow * ldp + (int64_t)ib * NB + lch * 8;
+  const unsigned short *gB = P + (int64_t)lrow * ldp + (int64_t)jb * NB + lch * 8;
+  i32x4 ra[3], rb[3];
+  auto gload = [&](int s) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int64_t off = (int64_t)p * plane_stride + (int64_t)s * BKH * ldp;
+      ra[p] = *reinterpret_cast<const i32x4 *>(gA + off);
+      rb[p] = *reinterpret_cast<const i32x4 *>(gB + off);
+    }
+  };
+  const int R = lds_row(lrow);
+  const int woff = R * ROWB + ((((lch >> 1) ^ (R & 7)) << 5) | ((lch & 1) << 4));
+  auto sstore = [&](int buf) {
+    unsigned char *b = lds + buf * 6 * PLANE_LDS + woff;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      *reinterpret_cast<i32x4 *>(b + p * PLANE_LDS) = ra[p];
+      *reinterpret_cast<i32x4 *>(b + (3 + p) * PLANE_LDS) = rb[p];
+    }
+  };
+  const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
+  const int rsw = (g & 1) * 4 + q;
+  const int r0 = ((g >> 1) * 16 + (g & 1) * 4 + q) * ROWB + p4 * 8, r1 = r0 + 8 * ROWB;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nst = K / BKH;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  if (nst > 1) gload(1);
+  for (int s = 0; s < nst; ++s) {
+    const unsigned char *cur = lds + (s & 1) * 6 * PLANE_LDS;
+    if (s + 1 < nst) sstore((s + 1) & 1);
+    if (s + 2 < nst) gload(s + 2);
+    auto frag = [&](int plane_op, int blk) -> bf16x8 {
+      const unsigned char *b = cur + plane_op * PLANE_LDS + ((blk ^ rsw) << 5);
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(b + r0));
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(b + r1));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    bf16x8 a[4], b[2], bh[2];
+    auto mm = [&](bf16x8 (&x)[4], bf16x8 (&y)[2]) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[mt], y[nt], acc[mt][nt], 0, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bh[i] = frag(3, wn * 2 + i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = frag(2, wm * 4 + i);
+    mm(a, bh);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = frag(1, wm * 4 + i);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i] = frag(4, wn * 2 + i);
+    mm(a, b);
+    mm(a, bh);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = frag(0, wm * 4 + i);
+    mm(a, b);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i] = frag(5, wn * 2 + i);
+    mm(a, b);
+    mm(a, bh);
+    __syncthreads();
+  }
+  // epilogue: tile -> LDS ([128][132] floats), then C -= tile with 16-byte accesses, a full 512-byte row per 32 lanes
+  float *stg = reinterpret_cast<float *>(lds);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        stg[(wm * 64 + mt * 16 + (lane >> 4) * 4 + r) * 132 + wn * 32 + nt * 16 + (lane & 15)] = acc[mt][nt][r];
+  __syncthreads();
+  float *C = M + ((int64_t)K + (int64_t)ib * NB) * ld + (int64_t)jb * NB;
+  const int crow = tid >> 5, ccol = (tid & 31) * 4;
+  float4 cv[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) cv[h] = *reinterpret_cast<const float4 *>(C + (int64_t)(crow + 16 * h) * ld + ccol);
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    const float4 sv = *reinterpret_cast<const float4 *>(stg + (crow + 16 * h) * 132 + ccol);
+    float4 o = {cv[h].x - sv.x, cv[h].y - sv.y, cv[h].z - sv.z, cv[h].w - sv.w};
+    *reinterpret_cast<float4 *>(C + (int64_t)(crow + 16 * h) * ld + ccol) = o;
+  }
+}
+
 int main() {
   const int n = 8192, K = 1024, TPR = 48;
   const int64_t ld = n + 128;
@@ -228,6 +333,25 @@ int main() {
   if (time_it("fp32 engine (16x16x4 f32)", [&]() { hipLaunchKernelGGL(k_f32_tiles, dim3(TPR * TPR), dim3(NTHREADS), 0, 0, M0, ld, K, TPR); })) return 1;
   if (time_it("bf16x3, 6 plane products", [&]() { hipLaunchKernelGGL((k_bf3_tiles<6>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
   if (time_it("bf16x3, 6 products, fragments reused", [&]() { hipLaunchKernelGGL((k_bf3_tiles<66>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bf3_tiles8), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 6 * PLANE_LDS));
+  {  // accuracy of the 8-wave form on a fresh copy of C
+    CK(hipMemcpy(M1, h.data(), elems * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_bf3_tiles8, dim3(TPR * TPR), dim3(512), 2 * 6 * PLANE_LDS, 0, P, ldp, plane_stride, M1, ld, K, TPR);
+    CK(hipDeviceSynchronize());
+    double e8 = 0;
+    for (auto &tt : tiles) {
+      const int ib = tt[0], jb = tt[1];
+      CK(hipMemcpy(c1.data(), M1 + ((int64_t)K + ib * NB) * ld, (size_t)NB * ld * 4, hipMemcpyDeviceToHost));
+      for (int i = 0; i < NB; i += 5)
+        for (int j = 0; j < NB; j += 3) {
+          double ref = h[((size_t)K + ib * NB + i) * ld + jb * NB + j];
+          for (int k = 0; k < K; ++k) ref -= (double)h[(size_t)k * ld + ib * NB + i] * (double)h[(size_t)k * ld + jb * NB + j];
+          e8 = fmax(e8, fabs(c1[(size_t)i * ld + jb * NB + j] - ref));
+        }
+    }
+    printf("8-wave double-buffered form: max |error| vs fp64 %.3e\n", e8);
+  }
+  if (time_it("bf16x3, 8 waves, 2 LDS stages", [&]() { hipLaunchKernelGGL(k_bf3_tiles8, dim3(TPR * TPR), dim3(512), 2 * 6 * PLANE_LDS, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
   if (time_it("  ablation: no global loads in the loop", [&]() { hipLaunchKernelGGL((k_bf3_tiles<66, 1>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
   if (time_it("  ablation: no loads, no LDS stores", [&]() { hipLaunchKernelGGL((k_bf3_tiles<66, 3>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
   if (time_it("bf16x3, 3 products (speed only)", [&]() { hipLaunchKernelGGL((k_bf3_tiles<3>), dim3(TPR * TPR), dim3(NTHREADS), 0, 0, P, ldp, plane_stride, M1, ld, K, TPR); })) return 1;
