@@ -149,6 +149,26 @@ int plmc_gemm_tn_f64(int mode, int M, int N, int K, const double *A, int64_t lda
                      int64_t ldb, int64_t strideB, double *C, int64_t ldc, int64_t strideC, int batch, void *stream);
 
 /*
+ * Eval-mode posterior, the reductions behind the augmented sweep (ProjectedGPModel.__call__, projected_lmc.py:1133-1155;
+ * gpytorch's DefaultPredictionStrategy behind ExactGPModel.__call__ :1134).
+ * plmc_posterior_moments: from the factor buffer after plmc_potrf_*(with_inverse = 0) on [ Khat | y | K*^T ]
+ *   (naug = 1 + ns): mean[latent][s] = v(s)^T z and vsq[latent][s] = |v(s)|^2 with z = column n_pad, v(s) = column
+ *   n_pad + 1 + s; the latent posterior is (mean, k(x*, x*) - vsq).  mean, vsq: q x ns, contiguous.
+ * plmc_mix_posterior: task-space moments of :1144 / :1152, mean[s][t] = sum_i mean_lat[i][s] Ht[i][t],
+ *   var[s][t] = sum_i var_lat[i][s] Ht[i][t]^2 + eps.  mean_lat, var_lat: q x ns; Ht: q x p; outputs ns x p.  With latent
+ *   sharding a rank passes its local latents (q = their number) and eps = 0, and adds eps after the all-reduce.
+ * Both HBM-bound; sums carried in fp64.
+ */
+int plmc_posterior_moments_f32(const float *A, int64_t n_pad, int64_t lda, int64_t strideA, int ns, float *mean,
+                               float *vsq, int q, void *stream);
+int plmc_posterior_moments_f64(const double *A, int64_t n_pad, int64_t lda, int64_t strideA, int ns, double *mean,
+                               double *vsq, int q, void *stream);
+int plmc_mix_posterior_f32(const float *mean_lat, const float *var_lat, const float *Ht, int q, int ns, int p,
+                           double eps, float *mean, float *var, void *stream);
+int plmc_mix_posterior_f64(const double *mean_lat, const double *var_lat, const double *Ht, int q, int ns, int p,
+                           double eps, double *mean, double *var, void *stream);
+
+/*
  * kinv_diag = diag(Khat^-1) = column sums of squares of W (q x n_pad): the leave-one-out variances
  * sigma2_i = 1 / [Khat^-1]_ii of `MultitaskGPModel.compute_loo` (:642-656) on the dense (n p) x (n p) system, where
  * the fused gradient kernel (single ARD kernel per matrix) does not apply.  HBM-bound, reads W once.

@@ -425,16 +425,34 @@ def exact_posterior(kind, X, ell, oscale, noise, y, Xs, full_cov=False):
     Xc, Xsc, ellc, osc, nzc = (_contig(t, dt) for t in (X, Xs, ell, oscale, noise))
     ws = get_workspace(n, q, 1 + ns, dt, dev, False)
     factorize_checked(kind, Xc, ellc, osc, nzc, _contig(y).reshape(q, 1, n), ws, Xs=Xsc)
-    aug = ws.A[:, :, ws.n_pad:ws.n_pad + 1 + ns]                # (q, n_pad, 1+ns) strided view
-    z = aug[:, :, 0]
-    V = aug[:, :, 1:]
-    mean = torch.einsum("qis,qi->qs", V, z)
+    # mean = V^T z and |v|^2 per test point: one pass over the augmented columns (plmc_posterior_moments)
+    mean = torch.empty(q, ns, dtype=dt, device=dev)
+    vsq = torch.empty(q, ns, dtype=dt, device=dev)
+    L.call("plmc_posterior_moments", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, ns, _hip.ptr(mean), _hip.ptr(vsq), q,
+           _hip.stream_ptr(dev))
     if full_cov:
+        V = ws.A[:, :, ws.n_pad + 1:ws.n_pad + 1 + ns]             # (q, n_pad, ns) strided view
         Kss = dense_cross(kind, Xsc, Xsc, ellc, osc)
         cov = Kss - V.transpose(-1, -2) @ V
         return mean, cov
     from .kernels import prior_diagonal
-    var = prior_diagonal(kind, Xsc, osc, q) - (V * V).sum(1)          # k(x*, x*) = 1 for the stationary kinds
+    var = prior_diagonal(kind, Xsc, osc, q) - vsq                      # k(x*, x*) = 1 for the stationary kinds
+    return mean, var
+
+
+def mix_posterior(mean_lat, var_lat, Ht, eps=0.0):
+    """Task-space moments of the projected model (projected_lmc.py:1144, :1152): mean (ns, p) = mean_lat^T Ht,
+    var (ns, p) = var_lat^T Ht^2 + eps, from latent moments (q, ns) and the mixing matrix Ht (q, p) -- plmc_mix_posterior."""
+    _hip.require_device(mean_lat, var_lat, Ht)
+    L = _hip.lib()
+    dt, dev = mean_lat.dtype, mean_lat.device
+    q, ns = mean_lat.shape
+    p = Ht.shape[1]
+    ml, vl, H = (_contig(t, dt) for t in (mean_lat, var_lat, Ht))
+    mean = torch.empty(ns, p, dtype=dt, device=dev)
+    var = torch.empty(ns, p, dtype=dt, device=dev)
+    L.call("plmc_mix_posterior", dt, _hip.ptr(ml), _hip.ptr(vl), _hip.ptr(H), q, ns, p, float(eps), _hip.ptr(mean), _hip.ptr(var),
+           _hip.stream_ptr(dev))
     return mean, var
 
 

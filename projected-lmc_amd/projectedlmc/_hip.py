@@ -37,6 +37,8 @@ _TYPED = {
     "plmc_lmc_kinv_grad": [_I, _P, _L, _L, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "plmc_kernel_vjp": [_I, _P, _I, _P, _I, _I, _P, _P, _P, _L, _L, _P, _P, _P, _I, _P],
     "plmc_qr_small": [_P, _I, _I, _L, _P, _L, _P, _L, _P],
+    "plmc_posterior_moments": [_P, _L, _L, _L, _I, _P, _P, _I, _P],
+    "plmc_mix_posterior": [_P, _P, _P, _I, _I, _I, _c.c_double, _P, _P, _P],
 }
 _PLAIN = {
     "plmc_version": ([], _I),

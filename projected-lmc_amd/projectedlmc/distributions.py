@@ -16,8 +16,9 @@ class KroneckerSumCovariance:
     needed by the drivers (experiments.py:329); `evaluate()` materialises for small cases.
     C_i given either as full (q,n,n) `cov` or as diagonal (q,n) `var`."""
 
-    def __init__(self, Ht, cov=None, var=None, eps=0.0, task_noise=None):
+    def __init__(self, Ht, cov=None, var=None, eps=0.0, task_noise=None, diag=None):
         self.Ht, self.cov, self.var, self.eps, self.task_noise = Ht, cov, var, eps, task_noise
+        self.diag = diag                                    # (n, p) diagonal incl. eps, if already mixed (plmc_mix_posterior)
         self.n = (cov if cov is not None else var).shape[-1]
         self.p = Ht.shape[-1]
 
@@ -27,11 +28,14 @@ class KroneckerSumCovariance:
 
     def add_task_noise(self, Sigma):
         tn = Sigma if self.task_noise is None else self.task_noise + Sigma
-        return KroneckerSumCovariance(self.Ht, self.cov, self.var, self.eps, tn)
+        return KroneckerSumCovariance(self.Ht, self.cov, self.var, self.eps, tn, self.diag)
 
     def diagonal(self, *a, **k):
-        v = self.var if self.var is not None else torch.diagonal(self.cov, dim1=-2, dim2=-1)   # (q,n)
-        dg = v.T @ (self.Ht * self.Ht) + self.eps                                              # (n,p)
+        if self.diag is not None:
+            dg = self.diag
+        else:
+            v = self.var if self.var is not None else torch.diagonal(self.cov, dim1=-2, dim2=-1)   # (q,n)
+            dg = v.T @ (self.Ht * self.Ht) + self.eps                                              # (n,p)
         if self.task_noise is not None:
             dg = dg + torch.diagonal(self.task_noise)[None, :]
         return dg.reshape(-1)

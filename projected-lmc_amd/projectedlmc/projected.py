@@ -323,17 +323,17 @@ class ProjectedGPModel(ExactGPModel):
         With latent sharding the partial sums are all-reduced (the one cross-latent reduction)."""
         mean_lat, v = self._latent_posterior(x, full_cov=full_cov)
         Ht = self.lmc_coefficients().detach()
+        v_diag = v if not full_cov else torch.diagonal(v, dim1=-2, dim2=-1)
         if self.latent_ids is not None:
-            Ht_loc = Ht[self.latent_ids]
-            mean = mean_lat.T @ Ht_loc
-            var = (v if not full_cov else torch.diagonal(v, dim1=-2, dim2=-1)).T @ (Ht_loc * Ht_loc)
+            # this rank's latents: partial sums of mean and variance (plmc_mix_posterior), then the one all-reduce
+            mean, var = _engine.mix_posterior(mean_lat, v_diag, Ht[self.latent_ids], 0.0)
             from . import parallel
             buf = torch.stack([mean, var])
             parallel.all_reduce_sum(buf)
             mean, var = buf[0], buf[1] + self.eps
             return MultitaskMultivariateNormal(mean, _DiagonalTaskCovariance(var))
-        mean = mean_lat.T @ Ht
-        cov = KroneckerSumCovariance(Ht, cov=v if full_cov else None, var=None if full_cov else v, eps=self.eps)
+        mean, var = _engine.mix_posterior(mean_lat, v_diag, Ht, self.eps)
+        cov = KroneckerSumCovariance(Ht, cov=v if full_cov else None, var=None if full_cov else v, eps=self.eps, diag=var)
         return MultitaskMultivariateNormal(mean, cov)
 
 

@@ -80,6 +80,8 @@ def _worker(rank, world, port, q, ret):
         mu, cov = gm.exact_gp_posterior(k, X_, ell, noise, y, Xs_, oscale, nu)
         return mu, (cov if full_cov else torch.diagonal(cov, dim1=-2, dim2=-1))
     _engine.exact_posterior = fake_posterior
+    # ... and of the mixing kernel (plmc_mix_posterior): the host logic under test is the shard / all-reduce around it
+    _engine.mix_posterior = lambda ml, vl, Ht, eps=0.0: (ml.T @ Ht, vl.T @ (Ht * Ht) + eps)
     Xs = 2 * torch.rand(9, d, generator=torch.Generator().manual_seed(5)) - 1
     m0.eval(); m1.eval()
     with torch.no_grad():
