@@ -431,9 +431,10 @@ def exact_posterior(kind, X, ell, oscale, noise, y, Xs, full_cov=False):
     L.call("plmc_posterior_moments", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, ns, _hip.ptr(mean), _hip.ptr(vsq), q,
            _hip.stream_ptr(dev))
     if full_cov:
-        V = ws.A[:, :, ws.n_pad + 1:ws.n_pad + 1 + ns]             # (q, n_pad, ns) strided view
+        V = ws.A[:, :, ws.n_pad + 1:ws.n_pad + 1 + ns]             # (q, n_pad, ns) strided view, K-major
         Kss = dense_cross(kind, Xsc, Xsc, ellc, osc)
-        cov = Kss - V.transpose(-1, -2) @ V
+        from ._dense import gemm_tn
+        cov = Kss - gemm_tn(V, V)                                   # V^T V on the library's tile engine (plmc_gemm_tn)
         return mean, cov
     from .kernels import prior_diagonal
     var = prior_diagonal(kind, Xsc, osc, q) - vsq                      # k(x*, x*) = 1 for the stationary kinds
