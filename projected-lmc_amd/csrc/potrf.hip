@@ -497,10 +497,12 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const Knobs &kn = knobs();                            // dev knobs: read once per process (api.hip)
   const double hthr = kn.half_tiles;
   const bool serial = kn.serial;
-  // With one or two latents the chain is the critical path: the bulk kernels then ask for 16 KB of LDS they do not use,
-  // which caps them at three workgroups per CU and leaves a slot per CU to the chain's small launches (q = 2: 11.4 ->
-  // 11.0 ms/step, q = 1: 7.8 -> 7.5; with many latents the bulk is the bound and the cap costs 1-2 %).
-  const unsigned bulk_lds = (unsigned)(kn.bulk_lds >= 0 ? kn.bulk_lds : (q <= 2 ? 16000 : 0));
+  // With one or two latents the chain is the critical path: the bulk kernels then ask for LDS they do not use, which caps
+  // their occupancy -- 16 KB (three workgroups per CU) at q = 2, 20 KB (two per CU: 46 KB of LDS and half the register file
+  // stay free, so a chain workgroup is placed at once instead of waiting for a bulk workgroup to retire) at q = 1.
+  // q = 2: 11.4 -> 11.0 ms/step; q = 1: sweep 5.55 -> 5.30 (16 KB) -> 5.03 ms (20 KB); 26 KB and more lose again (5.36);
+  // with many latents the bulk is the bound and a cap costs 1-2 %.
+  const unsigned bulk_lds = (unsigned)(kn.bulk_lds >= 0 ? kn.bulk_lds : (q == 1 ? 20000 : (q == 2 ? 16000 : 0)));
 
   auto diag = [&](int r, int g0, hipStream_t s) {
     ProfScope ps(PK_DIAG, s, q * (2.0 / 3.0) * nb3, q * 3.0 * nb * nb * esz);
