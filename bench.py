@@ -302,20 +302,25 @@ def main():
     # accumulate).  Same step, same K; its accuracy is checked at the same checkpoint states.
     option = None
     if world == 1 and not args.no_options:
-        with _hip.knob("PLMC_BF16X3", "1"):
-            _engine.free_workspaces()
-            for i in range(2):
-                step()
-            fence()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                step()
-            fence()
-            el = time.perf_counter() - t0
-            option = {"ms_per_step": 1e3 * el / args.steps, "iters_per_sec": args.steps / el}
-            if do_checks and st5 is not None:
-                gpu_checkpoint("after %d optimiser steps [bf16x3 option]" % n_check, st5, sorted({0, q - 1}))
-                model.train()
+        try:
+            with _hip.knob("PLMC_BF16X3", "1"):
+                _engine.free_workspaces()
+                for i in range(2):
+                    step()
+                fence()
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    step()
+                fence()
+                el = time.perf_counter() - t0
+                option = {"ms_per_step": 1e3 * el / args.steps, "iters_per_sec": args.steps / el}
+                if do_checks and st5 is not None:
+                    gpu_checkpoint("after %d optimiser steps [bf16x3 option]" % n_check, st5, sorted({0, q - 1}))
+                    model.train()
+        except Exception as exc:                            # the option must never cost the headline line
+            option = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            checkpoints[:] = [c for c in checkpoints if not c[0].endswith("[bf16x3 option]")]
+        finally:
             _engine.free_workspaces()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
