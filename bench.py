@@ -13,6 +13,7 @@ N GPUs: the q latent GPs are sharded across ranks (latent i -> rank i mod N), to
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          # N > 1 outside torch.distributed.run: starts the N ranks itself (self_launch)
 """
 import argparse
 import json
@@ -151,6 +152,24 @@ def cpu_baseline(X, Y, model_cpu_state, n_latents, budget_latents=4):
                            budget_latents, n_latents, n, n_latents, t))
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: run the N ranks as CHILD processes under
+    torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1, a free port) and pass on their exit code.  Rank 0's
+    JSON line goes straight to the inherited stdout.  This process never touches the GPU (nothing below `import torch`
+    has run yet) and never replaces itself: it waits for the children (a process that has initialised HIP must not exec)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "--", os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n_ranks)))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,18 +187,27 @@ def main():
                                                       "when no profile of this build is committed")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch `python bench.py --gpus N` (it starts the ranks itself) or "
+                         "torch.distributed.run --nproc-per-node N bench.py --gpus N" % (args.gpus, world))
     # PLMC_DIST_BACKEND=gloo is a rehearsal aid: several ranks sharing ONE GPU (RCCL refuses duplicate
     # devices) still exercise the sharded step end to end; the measured runs use "nccl" (= RCCL).
+    # PLMC_BENCH_DEVICE=cpu: launch rehearsal on a box without a GPU (rendezvous, sharding, all-reduce, JSON line).  The
+    # product has no CPU engine -- the first log-likelihood call raises on CPU tensors -- so this only gets anywhere inside
+    # tests/test_bench_launch.py, whose child processes replace that call by a test stand-in.
     backend = os.environ.get("PLMC_DIST_BACKEND", "nccl")
-    dev_index = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    on_gpu = os.environ.get("PLMC_BENCH_DEVICE", "cuda") != "cpu"
+    if on_gpu:
+        dev_index = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+    else:
+        dev = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -222,10 +250,12 @@ def main():
         return gl
 
     def fence():
-        torch.cuda.synchronize(dev)
+        if on_gpu:
+            torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if on_gpu:
+            torch.cuda.synchronize(dev)
 
     # Accuracy checkpoints (untimed): the HIP log-prob and its gradient w.r.t. EVERY parameter of a latent GP
     # (lengthscales, noise, all n projected targets) against the fp64 oracle at full size -- latent 0 at the initial
