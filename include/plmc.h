@@ -51,8 +51,15 @@ int         plmc_block(void);                 /* NB (128) */
 int64_t     plmc_pad(int64_t n);              /* n rounded up to a multiple of NB */
 int         plmc_max_dim(void);               /* largest input dimension d accepted by the fused kernels */
 const char *plmc_last_error(void);            /* text of the last error on the calling thread */
-int64_t     plmc_vd_blocks(int64_t n_pad, int64_t lda);   /* NB x NB blocks per latent the `Vd` argument of plmc_potrf_* must hold */
-/* Bytes of the `partials` scratch plmc_kinv_grad_* needs for (n_pad, q). */
+/* NB x NB blocks per latent the `Vd` argument of plmc_potrf_* must hold, for elements of `elem_bytes` (4 or 8) bytes.  The
+ * sizes never depend on the dev knobs (version 3: for 4-byte elements they always include the bf16 plane buffers of the
+ * bf16 engine, on or off).  plmc_vd_blocks(n_pad, lda) = the 4-byte count (the larger one: safe for both).
+ * ABI note: version 1 sized Vd as n_pad / NB blocks -- a caller built against it must re-query. */
+int64_t     plmc_vd_blocks_for(int64_t n_pad, int64_t lda, int elem_bytes);
+int64_t     plmc_vd_blocks(int64_t n_pad, int64_t lda);
+/* Bytes of the `partials` scratch plmc_kinv_grad_* needs for (n_pad, q): per-tile partial sums, and for 4-byte elements the
+ * bf16 planes of W (6 q n_pad^2 bytes).  plmc_grad_scratch_bytes = the 4-byte size. */
+int64_t     plmc_grad_scratch_bytes_for(int64_t n_pad, int q, int elem_bytes);
 int64_t     plmc_grad_scratch_bytes(int64_t n_pad, int q);
 
 /*
@@ -184,10 +191,10 @@ int plmc_w_diag_f64(const double *W, int64_t n_pad, int64_t ldw, int64_t strideW
  *   grad[latent][0..d-1] = d logp / d ell_k,  [d] = d/d noise,  [d+1] = d/d oscale   (double)
  * Optional outputs (may be NULL): Kinv (n_pad x ldk upper tiles, batch stride strideK),
  * kinv_diag (q x n_pad: diagonal of K^-1, for leave-one-out, compute_loo :1108-1119).
- * partials: scratch of plmc_grad_scratch_bytes(n_pad, q) bytes.
- * Opt-in (environment PLMC_BF16X3=1, fp32 entry point only): the W^T W products run on the bf16 matrix cores from a
- * three-plane bf16 split of W (x = hi + mid + lo, six plane products, fp32 accumulate); the planes live behind the
- * partials (plmc_grad_scratch_bytes grows by 6 q n_pad^2 bytes while the knob is set).  Off by default.
+ * partials: scratch of plmc_grad_scratch_bytes_for(n_pad, q, sizeof element) bytes.
+ * fp32 entry point with PLMC_BF16X3 on: the W^T W products run on the bf16 matrix cores from a three-plane bf16 split of W
+ * (x = hi + mid + lo exactly; six plane products into two fp32 accumulator levels: error vs fp64 0.3-0.4 x that of the
+ * fp32 MFMA chain, profiles/r03_split_numerics.txt); the planes live behind the partials.
  */
 int plmc_kinv_grad_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW,
                        const float *alpha, const float *X, int n, int d, const float *ell,
@@ -282,8 +289,9 @@ int plmc_qr_small_f64(const double *A, int m, int n, int64_t lda, double *Q, int
  * share those events); different devices are independent.  The Python layer calls from one thread per process.
  * Dev knobs are environment variables read once per process (PLMC_HALF_TILES, PLMC_GRP, PLMC_KINV_ORDER,
  * PLMC_SERIAL, PLMC_BULK_LDS); plmc_dev_reload_knobs() re-reads them (tests and bench.py change one and reload).  They change
- * schedules, never results.  The one knob that changes arithmetic is PLMC_BF16X3 (off by default; plmc_kinv_grad_f32, and the depth-(128 G) tail / head
- * updates inside plmc_potrf_f32, whose Vd scratch -- plmc_vd_blocks -- then also holds a rolling bf16 plane buffer).
+ * schedules; PLMC_GRP also changes the depth of the updates and with it the rounding.  PLMC_BF16X3 selects the arithmetic
+ * of the bulk fp32 products (plmc_kinv_grad_f32 and the depth-(128 G) tail / head updates inside plmc_potrf_f32): 1 = split
+ * operands on the bf16 matrix cores (bf3_engine.hpp), 0 = v_mfma_f32_16x16x4_f32.  Buffer sizes do not depend on any knob.
  * plmc_prof_mfma_rate: dense MFMA rate (TFLOP/s) of the current device measured with a bare instruction stream
  * (v_mfma_f32_16x16x4_f32 or _f64_16x16x4_f64, 4 waves per SIMD, no memory traffic); synchronous; `sink` = caller-owned
  * device scratch of at least 4 * CUs * 256 * sizeof(element) bytes.

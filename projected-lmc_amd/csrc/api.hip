@@ -36,7 +36,7 @@ static void load_knobs() {
   const char *h = getenv("PLMC_HALF_TILES"), *g = getenv("PLMC_GRP"), *o = getenv("PLMC_KINV_ORDER");
   g_knobs.half_tiles = h ? (atoi(h) == 1 ? 1e30 : (double)atoi(h)) : 640.0;
   g_knobs.grp = g ? atoi(g) : 0;
-  g_knobs.serial = getenv("PLMC_SERIAL") != nullptr;
+  g_knobs.serial = getenv("PLMC_SERIAL") && atoi(getenv("PLMC_SERIAL")) != 0;
   g_knobs.kinv_order = o ? atoi(o) : 4;
   g_knobs.bulk_lds = getenv("PLMC_BULK_LDS") ? atoi(getenv("PLMC_BULK_LDS")) : -1;
   g_knobs.bf16x3 = getenv("PLMC_BF16X3") && atoi(getenv("PLMC_BF16X3")) != 0;
@@ -133,7 +133,7 @@ ProfScope::~ProfScope() {
 }  // namespace plmc
 
 extern "C" {
-int plmc_version(void) { return 1; }
+int plmc_version(void) { return 3; }   // 3: Vd / gradient scratch sizes independent of the knobs (+ plmc_*_for), k8-ordered bf16 planes
 int plmc_block(void) { return plmc::NB; }
 int64_t plmc_pad(int64_t n) { return (n + plmc::NB - 1) / plmc::NB * plmc::NB; }
 int plmc_max_dim(void) { return plmc::MAX_DIM; }

@@ -265,121 +265,6 @@ __device__ __forceinline__ void tile_mainloop_burst(Acc<T, MT, NT> &acc, const T
   }
 }
 
-// ---- fp32 products on the bf16 matrix cores (opt-in, PLMC_BF16X3) ----------------------------------
-// Operands split ONCE into three bf16 planes x = hi + mid + lo (round to nearest even at every level, exact residuals:
-// 24 significand bits); a tile product is six plane products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation,
-// lo.hi + mid.mid + mid.hi + hi.mid + hi.lo + hi.hi (the dropped terms are below 2^-24 of a product).  The planes keep
-// the operands' K-major layout ([plane][k][column], leading dimension ldp elements, plane_stride elements between
-// planes); LDS holds one stage of 32 contraction rows per plane and operand, K-major as well, and the MFMA fragments
-// (8 consecutive k per lane) come out of the transposing ds_read_b64_tr_b16.  LDS rows are permuted (bits 2 and 3 of k
-// swapped: the eight rows a 32-lane half reads together become consecutive) and the 32-byte blocks of a row are
-// XOR-swizzled by (row & 7): conflict-free fragment reads on 256-byte rows.  The accumulator layout equals that of
-// v_mfma_f32_16x16x4_f32, so tile_writeback and the gradient epilogues take the result as they take tile_mainloop's.
-constexpr int BF3_BK = 32;                               // contraction rows per stage
-constexpr int BF3_ROWB = 256;                            // bytes per LDS row (128 bf16)
-constexpr int BF3_PLANE = BF3_BK * BF3_ROWB;             // 8 KB per plane and operand
-constexpr int BF3_LDS_BYTES = 6 * BF3_PLANE;             // 48 KB
-typedef short bf3_s16x4 __attribute__((ext_vector_type(4)));
-typedef short bf3_s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf3_bf16x8 __attribute__((ext_vector_type(8)));
-typedef int bf3_i32x4 __attribute__((ext_vector_type(4)));
-
-// x -> (hi, mid, lo), eight elements at a time (16-byte stores per plane)
-__device__ __forceinline__ void bf3_split8(const float (&x)[8], bf3_s16x8 &h, bf3_s16x8 &m, bf3_s16x8 &l) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 a = (__bf16)x[i];
-    const float r1 = x[i] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const float r2 = r1 - (float)b;
-    const __bf16 c = (__bf16)r2;
-    h[i] = __builtin_bit_cast(short, a);
-    m[i] = __builtin_bit_cast(short, b);
-    l[i] = __builtin_bit_cast(short, c);
-  }
-}
-
-// acc += sum_{k < K} A[k][0..127]^T B[k][0..127] from split operands.  Ap / Bp point at (first row of the K range, first
-// of the 128 columns) of plane 0; K % 32 == 0.  `lds`: BF3_LDS_BYTES, 16-byte aligned.  All 256 threads; ends with a barrier.
-__device__ __forceinline__ void tile_mainloop_bf3(Acc<float> &acc, const unsigned short *__restrict__ Ap, const unsigned short *__restrict__ Bp,
-                                                  int64_t ldp, int64_t plane_stride, int K, unsigned char *lds) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  // global -> registers: per plane and operand 512 chunks of 16 bytes per stage, two per thread (rows r and r + 16)
-  const int lrow = tid >> 4, lch = tid & 15;
-  const unsigned short *gA = Ap + (int64_t)lrow * ldp + lch * 8, *gB = Bp + (int64_t)lrow * ldp + lch * 8;
-  const int64_t step = (int64_t)BF3_BK * ldp, half = 16 * ldp;
-  bf3_i32x4 ra[3][2], rb[3][2];
-  auto gload = [&]() {
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        ra[p][h] = *reinterpret_cast<const bf3_i32x4 *>(gA + (int64_t)p * plane_stride + h * half);
-        rb[p][h] = *reinterpret_cast<const bf3_i32x4 *>(gB + (int64_t)p * plane_stride + h * half);
-      }
-    gA += step;
-    gB += step;
-  };
-  int woff[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int k = lrow + 16 * h, R = (k & 19) | ((k >> 1) & 4) | ((k << 1) & 8);
-    woff[h] = R * BF3_ROWB + ((((lch >> 1) ^ (R & 7)) << 5) | ((lch & 1) << 4));
-  }
-  // fragment addresses: lane group g = lane >> 4 holds k = 8 g .. 8 g + 7; inside it lane 4 q + p4 supplies the address
-  // of row q, columns 4 p4 .. 4 p4 + 3 of a 4 x 16 block; read j (0, 1) takes k = 8 g + 4 j + q
-  const int g = lane >> 4, q = (lane & 15) >> 2, p4 = lane & 3;
-  const int rsw = (g & 1) * 4 + q;
-  const int r0 = ((g >> 1) * 16 + (g & 1) * 4 + q) * BF3_ROWB + p4 * 8, r1 = r0 + 8 * BF3_ROWB;
-  auto frag = [&](int plane_op, int blk) -> bf3_bf16x8 {
-    const unsigned char *b = lds + plane_op * BF3_PLANE + ((blk ^ rsw) << 5);
-    const bf3_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf3_s16x4 *)(b + r0));
-    const bf3_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf3_s16x4 *)(b + r1));
-    return __builtin_bit_cast(bf3_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-  };
-  const int nst = K / BF3_BK;
-  gload();
-  for (int s = 0; s < nst; ++s) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        *reinterpret_cast<bf3_i32x4 *>(lds + p * BF3_PLANE + woff[h]) = ra[p][h];
-        *reinterpret_cast<bf3_i32x4 *>(lds + (3 + p) * BF3_PLANE + woff[h]) = rb[p][h];
-      }
-    __syncthreads();
-    if (s + 1 < nst) gload();
-    // six plane products, small terms first, every fragment read once per role: B.hi stays live while the A planes walk
-    // lo -> mid -> hi (56 fragment reads per stage instead of 96)
-    bf3_bf16x8 a[4], b[4], bh[4];
-    auto mm = [&](bf3_bf16x8 (&x)[4], bf3_bf16x8 (&y)[4]) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc.v[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[mt], y[nt], acc.v[mt][nt], 0, 0, 0);
-    };
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bh[i] = frag(3, wn * 4 + i);         // B.hi
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = frag(2, wm * 4 + i);          // A.lo
-    mm(a, bh);                                                       // lo.hi
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = frag(1, wm * 4 + i);          // A.mid
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = frag(4, wn * 4 + i);          // B.mid
-    mm(a, b);                                                        // mid.mid
-    mm(a, bh);                                                       // mid.hi
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = frag(0, wm * 4 + i);          // A.hi
-    mm(a, b);                                                        // hi.mid
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = frag(5, wn * 4 + i);          // B.lo
-    mm(a, b);                                                        // hi.lo
-    mm(a, bh);                                                       // hi.hi
-    __syncthreads();
-  }
-}
-
 // Coalesced epilogue: C[tile] (+)= acc through LDS.  The MFMA accumulator layout gives each lane 4-byte
 // pieces of 64-byte row segments (64 scalar loads + 64 scalar stores per lane for a read-modify-write);
 // transposing the tile through LDS in two 64-row halves turns that into 16-byte accesses of full
@@ -403,8 +288,11 @@ __device__ __forceinline__ void tile_mainloop_bf3(Acc<float> &acc, const unsigne
 // look-ahead" of round 1 ("Write-back hazard").  With soffset = 0 the compiler sees the hazard it knows
 // and pads it itself; tests/test_isa_hazards.py scans the built library for the unprotected pattern.
 enum { WB_STORE = 0, WB_ADD = 1, WB_SUB = 2, WB_STORE_NEG = 3 };   // C = acc | C += acc | C -= acc | C = -acc
+// `tid_` / `live`: for the 512-thread macro-tile kernels (bf3_engine.hpp), whose two halves of 256 threads each write one
+// 128 x 128 tile through their own staging area: tid_ = threadIdx.x & 255; a half without a tile (live = false) takes
+// part in the barriers only.
 template <typename T, int MODE, int MT = 4>
-__device__ __forceinline__ void tile_writeback(const Acc<T, MT> &acc, T *Cg, int64_t ldc, T *smem) {
+__device__ __forceinline__ void tile_writeback(const Acc<T, MT> &acc, T *Cg, int64_t ldc, T *smem, int tid_ = -1, bool live = true) {
   constexpr bool ADD = MODE == WB_ADD || MODE == WB_SUB;
   using vec_t = typename Traits<T>::vec_t;
   typedef int i32x4_t __attribute__((ext_vector_type(4)));
@@ -415,10 +303,10 @@ __device__ __forceinline__ void tile_writeback(const Acc<T, MT> &acc, T *Cg, int
   constexpr int RSTEP = NTHREADS / CPR;                // rows between a thread's chunks (8 / 4)
   constexpr int CH = 2;                                // chunks per pipeline stage
   constexpr int NHALF = MT / 2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = tid_ < 0 ? (int)threadIdx.x : tid_, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int row0 = tid / CPR, col0 = (tid % CPR) * EPV;
-  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(Cg, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(Cg, 0, __builtin_amdgcn_readfirstlane(live ? 0x7fffffff : 0), 0x00020000);   // 0 records: loads give 0, stores are dropped
   const unsigned voff = (unsigned)(((int64_t)row0 * ldc + col0) * (int64_t)sizeof(T));
   const unsigned rstep = (unsigned)((int64_t)RSTEP * ldc * (int64_t)sizeof(T));      // wave-uniform
   auto cload = [&](int half, int h0, vec_t (&v)[CH]) {

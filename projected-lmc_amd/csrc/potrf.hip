@@ -25,6 +25,7 @@
 #include "api_common.hpp"
 #include "covariance.hpp"
 #include "diag_block.hpp"
+#include "bf3_engine.hpp"
 #include "../../include/plmc.h"
 
 namespace plmc {
@@ -141,26 +142,29 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
   else tile_writeback<T, WB_SUB, MT>(acc, C, ldc, smem);               // C -= P^T P
 }
 
-// Opt-in (PLMC_BF16X3, fp32): the bulk trailing updates (tail, head rows; full tiles) with their depth-(128 G) products on
-// the bf16 matrix cores.  The operands are the panel rows of the current group, which k_gpanel_copy / k_vtrans also write
-// as three bf16 planes (x = hi + mid + lo) into a rolling two-group buffer `Pl` ([buffer][plane][128 GMAX rows][lda],
-// same column coordinates as the factor buffer); tile decoding, depth rules and the write-back are those of update_tile.
+// fp32, PLMC_BF16X3 (the fp32 default): the bulk trailing updates (tail, head rows) with their depth-(128 G) products on the
+// bf16 matrix cores (bf3_engine.hpp).  A workgroup of 512 threads takes the macro tile (block rows ib, ib + 1) x (column tile
+// bx).  The operands are the panel rows of the current group, which k_gpanel_copy / k_wtri_planes also write as k8-ordered
+// bf16 planes into a rolling two-group buffer `Pl` (per buffer b3_elems(128 GMAX, lda) elements, same column coordinates as
+// the factor buffer); tile decoding, skip and depth rules and the write-back are those of k_update, per half.
+// grid (nU + Taug + nW, (nrows + 1) / 2, q).
 template <int ROLE>
-__global__ __launch_bounds__(NTHREADS, 2) void k_update_bf3(float *A, int64_t lda, int64_t strideA, int ib0, int r_lo, int r_hi,
-                                                            ColMap<float> cm, int skip_ib, int skip_jb, const unsigned short *__restrict__ Pl,
-                                                            int64_t pl_lat_stride, int64_t plane_stride, int64_t wcol0) {
+__global__ __launch_bounds__(B3_NT, 2) void k_update_bf3(float *A, int64_t lda, int64_t strideA, int ib0, int nrows, int r_lo, int r_hi,
+                                                         ColMap<float> cm, int skip_ib, int skip_jb, const unsigned short *__restrict__ Pl,
+                                                         int64_t pl_lat_stride, int64_t wcol0) {
   if (ROLE == 3) __builtin_amdgcn_s_setprio(2);
-  extern __shared__ __align__(16) unsigned char dyn_pad[];             // occupancy cap of the bulk launches (few latents)
-  __shared__ __align__(16) unsigned char lds[BF3_LDS_BYTES];
-  const int bx = blockIdx.x, ib = ib0 + (int)blockIdx.y, lat = blockIdx.z;
+  __shared__ __align__(16) unsigned char lds[B3_LDS_BYTES];
+  const int bx = blockIdx.x, ibm = ib0 + 2 * (int)blockIdx.y, lat = blockIdx.z;
   int kr0 = r_lo * NB, depth = (r_hi - r_lo + 1) * NB;
   bool first = false;
   float *Al = A + (int64_t)lat * strideA;
   float *Cb = Al;
   int64_t ldc = lda, col0, colp;                                       // colp: column of the B operand in the plane buffer
+  bool v0 = true, v1 = ibm + 1 < ib0 + nrows;                          // which halves have a tile
   if (bx < cm.nU) {
     const int jb = cm.u0 + bx;
-    if (jb < ib || (ib < skip_ib && jb < skip_jb)) return;
+    v0 = jb >= ibm && !(ibm < skip_ib && jb < skip_jb);
+    v1 = v1 && jb >= ibm + 1 && !(ibm + 1 < skip_ib && jb < skip_jb);
     col0 = colp = (int64_t)jb * NB;
   } else if (bx < cm.nU + cm.Taug) {
     col0 = colp = cm.n_pad + (int64_t)(bx - cm.nU) * NB;
@@ -172,14 +176,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_update_bf3(float *A, int64_t ld
     colp = wcol0 + col0;
     if (cb >= r_lo) { first = true; kr0 = cb * NB; depth = (r_hi - cb + 1) * NB; }
   }
-  Acc<float> acc;
-  acc.zero();
-  const unsigned short *Pr = Pl + (int64_t)lat * pl_lat_stride + (int64_t)(kr0 - r_lo * NB) * lda;
-  tile_mainloop_bf3(acc, Pr + (int64_t)ib * NB, Pr + colp, lda, plane_stride, depth, lds);
-  float *C = Cb + (int64_t)ib * NB * ldc + col0;
-  if (first) tile_writeback<float, WB_STORE_NEG>(acc, C, ldc, reinterpret_cast<float *>(lds));
-  else tile_writeback<float, WB_SUB>(acc, C, ldc, reinterpret_cast<float *>(lds));
-  if (dyn_pad[0] == 123 && threadIdx.x == 99999) A[0] = 0.f;          // keeps the dynamic LDS request alive
+  if (!v0 && !v1) return;
+  Acc<float> acc0, acc1;
+  acc0.zero();
+  acc1.zero();
+  const unsigned short *Pr = Pl + (int64_t)lat * pl_lat_stride + b3_index(kr0 - r_lo * NB, 0, 0, lda);
+  b3_mainloop(acc0, acc1, Pr + (int64_t)ibm * NB * 8, Pr + colp * 8, lda, depth, lds);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc0.v[a][b] += acc1.v[a][b];
+  const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  float *C = Cb + (int64_t)(ibm + half) * NB * ldc + col0;
+  float *stg = reinterpret_cast<float *>(lds + half * B3_WB_BYTES);
+  const bool live = half ? v1 : v0;
+  if (first) tile_writeback<float, WB_STORE_NEG>(acc0, C, ldc, stg, (int)threadIdx.x & 255, live);   // first touch of a W tile
+  else tile_writeback<float, WB_SUB>(acc0, C, ldc, stg, (int)threadIdx.x & 255, live);
 }
 
 // Group panel: U^-T applied to the whole block row of the group as products with Vgg = Ugg^-1 (upper, K-major, leading
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(NTHREADS, (sizeof(T) == 8 || HEAD ? 2 : 4)) void k_
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_gpanel_copy(T *A, int64_t lda, int64_t strideA, int g0, ColMap<T> cm, const T *__restrict__ Pb,
                                                           int64_t ldp, int64_t strideP, unsigned short *__restrict__ Pl, int64_t pl_lat_stride,
-                                                          int64_t plane_stride, int64_t wcol0) {
+                                                          int64_t wcol0) {
   using vec_t = typename Traits<T>::vec_t;
   constexpr int EPV = Traits<T>::EPV, CPR = NB / EPV;
   const int lat = blockIdx.z, t = blockIdx.x, i = blockIdx.y;
@@ -253,22 +265,8 @@ __global__ __launch_bounds__(NTHREADS) void k_gpanel_copy(T *A, int64_t lda, int
   }
   const T *S = Pb + (int64_t)lat * strideP + (int64_t)i * NB * ldp + (int64_t)t * NB;
   if constexpr (sizeof(T) == 4) {
-    if (Pl) {                                              // PLMC_BF16X3: the finished rows also as three bf16 planes
-      unsigned short *P0 = Pl + (int64_t)lat * pl_lat_stride + (int64_t)i * NB * lda + colp;
-      for (int c = threadIdx.x; c < NB * (NB / 8); c += NTHREADS) {
-        const int r = c >> 4, col = (c & 15) * 8;
-        const float4 v0 = *reinterpret_cast<const float4 *>(S + (int64_t)r * ldp + col);
-        const float4 v1 = *reinterpret_cast<const float4 *>(S + (int64_t)r * ldp + col + 4);
-        *reinterpret_cast<float4 *>(D + (int64_t)r * ldd + col) = v0;
-        *reinterpret_cast<float4 *>(D + (int64_t)r * ldd + col + 4) = v1;
-        const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        bf3_s16x8 h, m, l;
-        bf3_split8(x, h, m, l);
-        unsigned short *o = P0 + (int64_t)r * lda + col;
-        *reinterpret_cast<bf3_s16x8 *>(o) = h;
-        *reinterpret_cast<bf3_s16x8 *>(o + plane_stride) = m;
-        *reinterpret_cast<bf3_s16x8 *>(o + 2 * plane_stride) = l;
-      }
+    if (Pl) {                                              // PLMC_BF16X3: the finished rows also as k8-ordered bf16 planes
+      b3_split_block<true>(S, ldp, Pl + (int64_t)lat * pl_lat_stride + b3_index((int64_t)i * NB, 0, colp, lda), lda, D, ldd, threadIdx.x);
       return;
     }
   }
@@ -281,10 +279,9 @@ __global__ __launch_bounds__(NTHREADS) void k_gpanel_copy(T *A, int64_t lda, int
 // Transpose of the group's inverse triangle: Vg[k][i] = Wg[i][k]^T for block pairs k <= i < G (Vg = Ugg^-1, upper,
 // K-major for the tile engine) and, when the inverse factor is wanted, the copy of Wg[i][k] into the factor buffer's
 // W columns (block row g0 + i, block column g0 + k).  grid (G (G + 1) / 2, q), 32 x 32 sub-tiles through LDS.
-template <typename T, bool PLANES = false>
+template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, int64_t strideG, T *__restrict__ Vg, int G, T *Wout,
-                                                     int64_t ldw, int64_t strideW, unsigned short *__restrict__ Pl, int64_t pl_lat_stride,
-                                                     int64_t plane_stride, int64_t pl_ld, int64_t pl_col0) {
+                                                     int64_t ldw, int64_t strideW) {
   __builtin_amdgcn_s_setprio(3);
   __shared__ T tile[32][33];
   const int lat = blockIdx.y;
@@ -293,8 +290,6 @@ __global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, i
   const T *src = Wg + (int64_t)lat * strideG + (int64_t)i * NB * LDG + (int64_t)k * NB;
   T *dst = Vg + (int64_t)lat * strideG + (int64_t)k * NB * LDG + (int64_t)i * NB;
   T *wo = Wout ? Wout + (int64_t)lat * strideW + (int64_t)i * NB * ldw + (int64_t)k * NB : nullptr;
-  // PLMC_BF16X3 (fp32): the triangle's rows also as three bf16 planes (row i NB + r, column pl_col0 + k NB + c)
-  unsigned short *po = (PLANES && Pl) ? Pl + (int64_t)lat * pl_lat_stride + (int64_t)i * NB * pl_ld + pl_col0 + (int64_t)k * NB : nullptr;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
   for (int bi = 0; bi < NB; bi += 32)
     for (int bk = 0; bk < NB; bk += 32) {
@@ -303,24 +298,25 @@ __global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, i
         const T v = src[(int64_t)(bi + ty + r) * LDG + bk + tx];
         tile[ty + r][tx] = v;
         if (wo) wo[(int64_t)(bi + ty + r) * ldw + bk + tx] = v;
-        if constexpr (PLANES && sizeof(T) == 4) {
-          if (po) {
-            const __bf16 a = (__bf16)v;
-            const float r1 = v - (float)a;
-            const __bf16 b = (__bf16)r1;
-            const __bf16 c = (__bf16)(r1 - (float)b);
-            unsigned short *o = po + (int64_t)(bi + ty + r) * pl_ld + bk + tx;
-            o[0] = __builtin_bit_cast(unsigned short, a);
-            o[plane_stride] = __builtin_bit_cast(unsigned short, b);
-            o[2 * plane_stride] = __builtin_bit_cast(unsigned short, c);
-          }
-        }
       }
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < 32; r += 8) dst[(int64_t)(bk + ty + r) * LDG + bi + tx] = tile[tx][ty + r];
       __syncthreads();
     }
+}
+
+// PLMC_BF16X3 (fp32): the group's inverse triangle W[g0 + i][g0 + k] (k <= i < G, already in the factor buffer's W columns:
+// k_vtrans) as k8-ordered bf16 planes of the rolling buffer (rows 128 i .., column wcol0 + 128 (g0 + k)): the operands of the
+// first-touch W tiles of the tail / head updates.  Off the chain's stream.  grid (G (G + 1) / 2, q).
+__global__ __launch_bounds__(NTHREADS) void k_wtri_planes(const float *__restrict__ WA, int64_t lda, int64_t strideA, int g0,
+                                                          unsigned short *__restrict__ Pl, int64_t pl_lat_stride, int64_t wcol0) {
+  const int lat = blockIdx.y;
+  int i = 0, k = (int)blockIdx.x;
+  while (k > i) { k -= i + 1; ++i; }
+  b3_split_block<false>(WA + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + (int64_t)(g0 + k) * NB, lda,
+                        Pl + (int64_t)lat * pl_lat_stride + b3_index((int64_t)i * NB, 0, wcol0 + (int64_t)(g0 + k) * NB, lda), lda, nullptr, 0,
+                        threadIdx.x);
 }
 
 // K^-1 accumulation inside the sweep (with_inverse = 2).  Khat^-1 = W^T W = sum over groups of W[R]^T W[R] (R = the block
@@ -472,7 +468,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const hipStream_t st = (hipStream_t)stream;
   const int m = (int)(n_pad / NB);
   const int Taug = (int)(naug_pad / NB);
-  const int64_t strideV = plmc_vd_blocks(n_pad, lda) * (int64_t)NB * NB; // per latent: m diagonal inverses + group scratch
+  const int64_t strideV = plmc_vd_blocks_for(n_pad, lda, (int)sizeof(T)) * (int64_t)NB * NB; // per latent: m diagonal inverses + group scratch
   const int64_t wcol0 = n_pad + naug_pad;
   const double nb = (double)NB, nb3 = nb * nb * nb, esz = sizeof(T);
   // group scratch of latent 0 (batch stride strideV): the inverse triangle Wg and two transposed copies (ping-pong:
@@ -484,12 +480,12 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   T *const Kd = Vd + strideV - (int64_t)m * NB * NB;                    // diagonal tiles of the accumulated K^-1: last m blocks
   // PLMC_BF16X3 (fp32, opt-in): rolling two-group buffer of the panel rows as three bf16 planes, behind the bulk panel buffer
   const bool bf3 = sizeof(T) == 4 && knobs().bf16x3;
-  const int64_t pl_plane = (int64_t)GMAX * NB * lda;                    // elements between planes
+  const int64_t pl_buf = b3_elems((int64_t)GMAX * NB, lda);             // 16-bit elements of one group's planes (k8 order)
   unsigned short *const Pl0 = bf3 ? reinterpret_cast<unsigned short *>(Pbulk + (int64_t)GMAX * NB * lda) : nullptr;
   const int64_t pl_lat = strideV * (int64_t)(sizeof(T) / 2);            // latent stride in 16-bit elements
   const int grp_rows = (knobs().grp > 0 && knobs().grp < GMAX) ? knobs().grp : GMAX;   // block rows per group (as below)
   auto planes = [&](int g0) -> unsigned short * {                       // buffer of the group that starts at block row g0
-    return bf3 ? Pl0 + (int64_t)((g0 / grp_rows) & 1) * 3 * pl_plane : nullptr;
+    return bf3 ? Pl0 + (int64_t)((g0 / grp_rows) & 1) * pl_buf : nullptr;
   };
   const bool kacc_on = with_inverse == 2;
   T *const WA = with_inverse ? A + wcol0 : (T *)nullptr;                // inverse-factor columns of the factor buffer
@@ -567,10 +563,11 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     if constexpr (sizeof(T) == 4) {
       if (use_bf3) {
         const unsigned short *pl = planes(r_lo);
+        const dim3 gridb(Cn, (nrows + 1) / 2, q);
         if (cls == PK_TRAIL)
-          hipLaunchKernelGGL((k_update_bf3<0>), grid, dim3(NTHREADS), dyn, s, A, lda, strideA, ib0, r_lo, r_hi, cm, skip_ib, skip_jb, pl, pl_lat, pl_plane, wcol0);
+          hipLaunchKernelGGL((k_update_bf3<0>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cm, skip_ib, skip_jb, pl, pl_lat, wcol0);
         else
-          hipLaunchKernelGGL((k_update_bf3<3>), grid, dim3(NTHREADS), dyn, s, A, lda, strideA, ib0, r_lo, r_hi, cm, skip_ib, skip_jb, pl, pl_lat, pl_plane, wcol0);
+          hipLaunchKernelGGL((k_update_bf3<3>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cm, skip_ib, skip_jb, pl, pl_lat, wcol0);
         return;
       }
     }
@@ -599,7 +596,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
                            (int64_t)LDG, strideV, Pb, ldp, strideV);
     }
     hipLaunchKernelGGL((k_gpanel_copy<T>), dim3(nt, G, q), dim3(NTHREADS), 0, s, A, lda, strideA, g0, cm, (const T *)Pb, ldp, strideV,
-                       planes(g0), pl_lat, pl_plane, wcol0);
+                       planes(g0), pl_lat, wcol0);
   };
 
   // whole-sweep bracket on the caller's stream (the per-kernel records of overlapped kernels add up to
@@ -653,12 +650,15 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   auto vtrans = [&](int gi, hipStream_t s) {
     const int g0 = G0(gi), G = G0(gi + 1) - g0;
     T *wo = WA ? WA + (int64_t)g0 * NB * lda + (int64_t)g0 * NB : (T *)nullptr;
-    if (bf3 && WA)
-      hipLaunchKernelGGL((k_vtrans<T, true>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)Wg, strideV, Vg2[gi & 1], G, wo, lda,
-                         strideA, planes(g0), pl_lat, pl_plane, lda, wcol0 + (int64_t)g0 * NB);
-    else
-      hipLaunchKernelGGL((k_vtrans<T, false>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)Wg, strideV, Vg2[gi & 1], G, wo, lda,
-                         strideA, (unsigned short *)nullptr, pl_lat, pl_plane, lda, wcol0 + (int64_t)g0 * NB);
+    hipLaunchKernelGGL((k_vtrans<T>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)Wg, strideV, Vg2[gi & 1], G, wo, lda, strideA);
+  };
+  // PLMC_BF16X3: planes of the group's inverse triangle (read back from the W columns k_vtrans wrote; any stream behind it)
+  auto wtri_planes = [&](int gi, hipStream_t s) {
+    if constexpr (sizeof(T) == 4) {
+      if (!bf3 || !WA) return;
+      const int g0 = G0(gi), G = G0(gi + 1) - g0;
+      hipLaunchKernelGGL(k_wtri_planes, dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const float *)WA, lda, strideA, g0, planes(g0), pl_lat, wcol0);
+    }
   };
 
   auto kacc = [&](int gi, hipStream_t s) {
@@ -685,6 +685,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       const int g0 = G0(gi), g1 = G0(gi + 1);
       chain(gi, st);
       vtrans(gi, st);
+      wtri_planes(gi, st);
       gpanel(g0, g1 - g0, cm_buf(g1, m - g1, Taug, 0, g0), Vg2[gi & 1], st, 0);
       if (bf3) {             // as under the look-ahead: the next group's triangle on the fp32 MFMAs, the rest on bf16x3
         const int g2 = G0(gi + 2);
@@ -725,6 +726,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     update(g1, g2 - g1, g0, g1 - 1, cm_buf(g1, g2 - g1, 0, 0, 0), C, PK_TRAIL_HEAD, 0, 0, true);   // U1: next triangle
 
     (void)hipStreamWaitEvent(H, e_v, 0);
+    wtri_planes(gi, H);
     gpanel(g0, G, cm_buf(g2, m - g2, Taug, 0, g0), Vg, H, 0);                   // rest of the panel columns
     (void)hipEventRecord(e_p, H);
     (void)hipStreamWaitEvent(H, e_gh, 0);
@@ -781,11 +783,15 @@ int w_diag_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, T *kinv
 }  // namespace plmc
 
 extern "C" {
-int64_t plmc_vd_blocks(int64_t n_pad, int64_t lda) {
-  // PLMC_BF16X3: + the rolling plane buffer, 2 groups x 3 planes x (128 GMAX) x lda 16-bit elements = 3 GMAX lda / 128 fp32 blocks
-  const int64_t planes = plmc::knobs().bf16x3 ? 3 * plmc::GMAX * ((lda + plmc::NB - 1) / plmc::NB) : 0;
-  return 2 * (n_pad / plmc::NB) + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ((lda + plmc::NB - 1) / plmc::NB) + planes;
+// Vd blocks per latent: m diagonal inverses + the fixed group scratch + the bulk panel buffer (GMAX block rows of lda) + m
+// diagonal K^-1 tiles; for 4-byte elements also the rolling bf16 plane buffer of the bf16 engine (2 groups x 3 planes x
+// 128 GMAX rows x lda 16-bit elements = 3 GMAX lda / 128 fp32 blocks) -- whether or not PLMC_BF16X3 is on, so that a
+// workspace never depends on a knob.
+int64_t plmc_vd_blocks_for(int64_t n_pad, int64_t lda, int elem_bytes) {
+  const int64_t ldb = (lda + plmc::NB - 1) / plmc::NB;
+  return 2 * (n_pad / plmc::NB) + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ldb + (elem_bytes == 4 ? 3 * plmc::GMAX * ldb : 0);
 }
+int64_t plmc_vd_blocks(int64_t n_pad, int64_t lda) { return plmc_vd_blocks_for(n_pad, lda, 4); }
 int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet,
                    int *info, int with_inverse, int q, void *stream) {
   return plmc::potrf_impl<float>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, stream);

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include "api_common.hpp"
 #include "covariance.hpp"
+#include "bf3_engine.hpp"
 #include "../../include/plmc.h"
 
 namespace plmc {
@@ -39,13 +40,13 @@ template <int DCAP> struct GradLds {
 //   weight 2 above the diagonal, 1 on it (where df = 0, so it adds nothing to the lengthscale sums), 0 below / outside n.
 //     g[k] += os sum_ij wt w base df_k^2,   g_os += sum wt w val,   g_noise += sum_ii w,   w = alpha_i alpha_j - Kinv_ij.
 template <typename T, int DCAP, int KIND, bool INTERIOR>
-__device__ __forceinline__ void grad_tile_small(const Acc<T> &acc, T *smem, T os, int ib, int jb, int n, int lat, int64_t n_pad,
+__device__ __forceinline__ void grad_tile_small(const Acc<T> &acc, T *smem, const int tid, T os, int ib, int jb, int n, int lat, int64_t n_pad,
                                                 T *Kinv, int64_t ldk, int64_t strideK, T *kinv_diag, T (&g)[DCAP],
                                                 T &g_noise, T &g_os) {
   typedef Pair<T> T2;
   typedef GradLds<DCAP> L;
   constexpr int NP = DCAP / 2;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   T2 g2[NP];
 #pragma unroll
@@ -122,18 +123,28 @@ __device__ __forceinline__ void grad_tile_small(const Acc<T> &acc, T *smem, T os
 // occupancy floor: fp32 with up to 8 input dimensions fits 128 registers (4 waves per SIMD, as the update kernels)
 template <typename T, int DCAP> constexpr int KG_MIN_WAVES = sizeof(T) == 8 ? 2 : (DCAP <= 8 ? 4 : (DCAP <= 16 ? 2 : 1));
 
+// ---- gradient epilogue of one 128 x 128 tile (ib, jb) of K^-1 held in `acc` (the accumulator layout of the tile engines),
+// as a function: for the halves of the 512-thread macro-tile kernel (tid = threadIdx.x & 255; each half on its own tile with
+// its own `smem` of tile_smem_elems<T>() elements).  Both halves execute the same barriers; a half without a tile
+// (live = false) stages zeros and writes nothing.  Body: kinv_epilogue.inc.
+template <typename T, int DCAP, bool SPLINE>
+__device__ __forceinline__ void kinv_tile_epilogue(const Acc<T> &acc, T *smem, const int tid, const bool live, int kind, int ib, int jb, int lat,
+                                                   int m, int64_t n_pad, const T *__restrict__ alpha, const T *__restrict__ X, int n, int d,
+                                                   const T *__restrict__ ell, const T *__restrict__ oscale, T *Kinv, int64_t ldk,
+                                                   int64_t strideK, T *kinv_diag, double *__restrict__ partials, int plain) {
+  if (!live) { n = 0; Kinv = nullptr; kinv_diag = nullptr; }       // every element predicate below is then false
+#include "kinv_epilogue.inc"
+}
+
 // SPLINE (general epilogue only): the product-form spline kernel gets its own instantiation, so that its extra live
 // values do not raise the register pressure (and the scratch) of the stationary kernels' code.
-// BF3 (fp32, opt-in): the W^T W product of the tile runs on the bf16 matrix cores from the three-plane split copy of W
-// (`Wp`: [latent][plane][n_pad][n_pad] bf16, written by k_split_w) -- tile_mainloop_bf3, gemm_core.hpp.
-template <typename T, int DCAP, bool SPLINE = false, bool BF3 = false>
-__global__ __launch_bounds__(NTHREADS, (BF3 ? (DCAP <= 16 ? 2 : 1) : KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad(int kind, const T *__restrict__ W, int64_t n_pad, int64_t ldw,
+template <typename T, int DCAP, bool SPLINE = false>
+__global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad(int kind, const T *__restrict__ W, int64_t n_pad, int64_t ldw,
                                                          int64_t strideW, const T *__restrict__ alpha,
                                                          const T *__restrict__ X, int n, int d,
                                                          const T *__restrict__ ell, const T *__restrict__ oscale,
                                                          T *Kinv, int64_t ldk, int64_t strideK, T *kinv_diag,
-                                                         double *__restrict__ partials, int nlat, int plain,
-                                                         const unsigned short *__restrict__ Wp) {
+                                                         double *__restrict__ partials, int nlat, int plain) {
   const int m = (int)(n_pad / NB);
   int lat, ib, jb;
   if (plain >= 4) {                    // longest tiles first: jb ascending outermost, latent fastest
@@ -148,212 +159,53 @@ __global__ __launch_bounds__(NTHREADS, (BF3 ? (DCAP <= 16 ? 2 : 1) : KG_MIN_WAVE
     jb = blockIdx.x; ib = blockIdx.y; lat = blockIdx.z;
     if (jb < ib) return;
   } else if (!xcd_tri_decode(blockIdx.x, m, nlat, lat, ib, jb)) return;   // XCD-dealt 8 x 8 super-tiles
-  constexpr int SMEM_ELEMS = (BF3 && BF3_LDS_BYTES / (int)sizeof(T) > tile_smem_elems<T>()) ? BF3_LDS_BYTES / (int)sizeof(T) : tile_smem_elems<T>();
-  __shared__ __align__(16) T smem[SMEM_ELEMS];
+  __shared__ __align__(16) T smem[tile_smem_elems<T>()];
   const T *Wl = W + (int64_t)lat * strideW + (int64_t)jb * NB * ldw;
   Acc<T> acc;
   acc.zero();
-  if constexpr (BF3) {
-    static_assert(sizeof(T) == 4, "bf16x3 products stand in for fp32 products");
-    const unsigned short *Pl = Wp + (int64_t)lat * 3 * n_pad * n_pad + (int64_t)jb * NB * n_pad;
-    tile_mainloop_bf3(acc, Pl + (int64_t)ib * NB, Pl + (int64_t)jb * NB, n_pad, n_pad * n_pad, (int)(n_pad - (int64_t)jb * NB),
-                      reinterpret_cast<unsigned char *>(smem));
-  } else {
-    tile_mainloop<T, false, true>(acc, Wl + (int64_t)ib * NB, ldw, Wl + (int64_t)jb * NB, ldw, (int)(n_pad - (int64_t)jb * NB),
-                                  smem);
-  }
-
-  // ---- epilogue: stage scaled inputs u = x / ell and alpha for the tile's rows and columns
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const T *el = ell + (int64_t)lat * d;
-  const T os = oscale ? oscale[lat] : T(1);
-  // per-lane partial sums over the lane's 64 tile elements stay in T (fp32 on the fp32 path: 64 terms,
-  // relative error ~4e-6, far inside the fp32 gradient tolerance); everything across lanes, waves and
-  // tiles is reduced in fp64.
-  T g_noise = T(0), g_os = T(0);
-  auto wave_sum = [&](double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-  };
-  double *red;                                         // [4][GP] per-wave sums, reduced across waves at the end
-
-  if constexpr (DCAP <= 8) {
-    typedef GradLds<DCAP> L;
-    T g[DCAP];
-#pragma unroll
-    for (int k = 0; k < DCAP; ++k) g[k] = T(0);
-    static_assert(L::END <= tile_smem_elems<T>(), "gradient epilogue LDS plan");
-    for (int e = tid; e < NB * DCAP; e += NTHREADS) {     // unused dimensions and rows beyond n are staged as zeros
-      const int r = e / DCAP, k = e % DCAP;
-      const int gi = ib * NB + r, gj = jb * NB + r;
-      const T inv = k < d ? T(1) / el[k] : T(0);
-      smem[L::UI + r * L::LDI + k] = (k < d && gi < n) ? X[(int64_t)gi * d + k] * inv : T(0);
-      smem[L::UJ + r * L::LDI + k] = (k < d && gj < n) ? X[(int64_t)gj * d + k] * inv : T(0);
-    }
-    if (tid < NB) {
-      smem[L::AI + tid] = alpha[(int64_t)lat * n_pad + ib * NB + tid];
-      smem[L::AJ + tid] = alpha[(int64_t)lat * n_pad + jb * NB + tid];
-    }
-    __syncthreads();
-    const bool interior = ib < jb && (jb + 1) * NB <= n && !Kinv && !kinv_diag && plain != 5;
-#define PLMC_GRAD_TILE(KIND, INT) \
-  grad_tile_small<T, DCAP, KIND, INT>(acc, smem, os, ib, jb, n, lat, n_pad, Kinv, ldk, strideK, kinv_diag, g, g_noise, g_os)
-    if (interior) {
-      if (kind == K_RBF) PLMC_GRAD_TILE(K_RBF, true);
-      else if (kind == K_MATERN12) PLMC_GRAD_TILE(K_MATERN12, true);
-      else if (kind == K_MATERN32) PLMC_GRAD_TILE(K_MATERN32, true);
-      else if (kind == K_MATERN52) PLMC_GRAD_TILE(K_MATERN52, true);
-      else PLMC_GRAD_TILE(K_SPLINE, false);            // rare kernel: one (predicated) instantiation serves all tiles
-    } else {
-      if (kind == K_RBF) PLMC_GRAD_TILE(K_RBF, false);
-      else if (kind == K_MATERN12) PLMC_GRAD_TILE(K_MATERN12, false);
-      else if (kind == K_MATERN32) PLMC_GRAD_TILE(K_MATERN32, false);
-      else if (kind == K_MATERN52) PLMC_GRAD_TILE(K_MATERN52, false);
-      else PLMC_GRAD_TILE(K_SPLINE, false);
-    }
-#undef PLMC_GRAD_TILE
-    __syncthreads();                                   // the sums reuse the staging area
-    red = reinterpret_cast<double *>(smem);
-#pragma unroll
-    for (int k = 0; k < DCAP; ++k) {
-      const double s = wave_sum((double)g[k]);
-      if (lane == 0) red[wave * GP + k] = s;
-    }
-  } else {
-  // d > 8: general tile code.  mt / nt are unrolled (static accumulator indices); the register r inside an MFMA tile
-  // is picked with a select chain -- a runtime-indexed accumulator would be demoted to scratch memory.
-  // fp32 keeps the row's inputs, the squared differences and all DCAP lengthscale sums in registers (one pass over the
-  // tile).  fp64 (64 accumulator doubles = 128 registers at 2 waves per SIMD) walks the tile once per group of GH = 8
-  // dimensions with 8 sums live and reads the inputs from LDS where they are needed; the covariance value is
-  // recomputed per pass.  Either way nothing is spilled.
-  constexpr bool KEEP = sizeof(T) == 4;
-  constexpr int GH = KEEP ? DCAP : 8;
-  constexpr int KD = KEEP ? DCAP : 1;
-  const int ldu = d + 1;
-  T *ui = smem;                        // [128][ldu]
-  T *uj = ui + NB * ldu;               // [128][ldu]
-  T *ai = uj + NB * ldu;               // [128]
-  T *aj = ai + NB;                     // [128]
-  red = reinterpret_cast<double *>(aj + NB);           // own area: filled pass by pass
-  static_assert((2 * NB * (MAX_DIM + 1) + 2 * NB) * sizeof(T) + 4 * GP * sizeof(double) <= tile_smem_elems<T>() * sizeof(T),
-                "general gradient epilogue LDS plan");
-  for (int e = tid; e < NB * d; e += NTHREADS) {
-    int r = e / d, k = e % d;
-    int gi = ib * NB + r, gj = jb * NB + r;
-    T inv = T(1) / el[k];
-    ui[r * ldu + k] = gi < n ? X[(int64_t)gi * d + k] * inv : T(0);
-    uj[r * ldu + k] = gj < n ? X[(int64_t)gj * d + k] * inv : T(0);
-  }
-  if (tid < NB) {
-    ai[tid] = alpha[(int64_t)lat * n_pad + ib * NB + tid];
-    aj[tid] = alpha[(int64_t)lat * n_pad + jb * NB + tid];
-  }
-  __syncthreads();
-#pragma unroll 1
-  for (int k0 = 0; k0 < DCAP; k0 += GH) {
-    T g[GH];
-#pragma unroll
-    for (int k = 0; k < GH; ++k) g[k] = T(0);
-    const bool first = k0 == 0;
-    if (first || (k0 < d && !SPLINE)) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll 1
-        for (int r = 0; r < 4; ++r) {
-          const int row = tile_row<T>(wm, mt, lane, r);
-          const int gi = ib * NB + row;
-          T xi[KD];
-          const T *uir = ui + row * ldu;
-          if constexpr (KEEP) {
-#pragma unroll
-            for (int k = 0; k < DCAP; ++k) xi[k] = k < d ? uir[k] : T(0);
-          }
-          const T a_i = ai[row];
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const int col = tile_col(wn, nt, lane);
-            const int gj = jb * NB + col;
-            const auto &av = acc.v[mt][nt];
-            const T kin = r == 0 ? av[0] : (r == 1 ? av[1] : (r == 2 ? av[2] : av[3]));
-            if (first) {
-              if (Kinv && gj >= gi) Kinv[(int64_t)lat * strideK + (int64_t)gi * ldk + gj] = kin;
-              if (kinv_diag && gi == gj) kinv_diag[(int64_t)lat * n_pad + gi] = kin;
-            }
-            if (gi < n && gj < n && gj >= gi) {
-              const T wij = a_i * aj[col] - kin;
-              const T *ujc = uj + col * ldu;
-              T df2[KD];
-              T r2 = T(0);
-              if constexpr (KEEP) {
-#pragma unroll
-                for (int k = 0; k < DCAP; ++k) {
-                  T df = k < d ? xi[k] - ujc[k] : T(0);
-                  df2[k] = df * df;
-                  r2 += df2[k];
-                }
-              } else {
-#pragma unroll 4
-                for (int k = 0; k < d; ++k) { const T df = uir[k] - ujc[k]; r2 += df * df; }
-              }
-              T val, base;
-              if constexpr (SPLINE) {
-                val = T(1);
-                if constexpr (KEEP) {
-#pragma unroll
-                  for (int k = 0; k < DCAP; ++k) val *= k < d ? spline_factor(xi[k], ujc[k]) : T(1);
-                } else {
-#pragma unroll 4
-                  for (int k = 0; k < d; ++k) val *= spline_factor(uir[k], ujc[k]);
-                }
-                base = T(0);
-              } else {
-                kern_value_base_fast(kind, r2, val, base);
-              }
-              if (gi == gj) {
-                if (first) { g_noise += wij; g_os += wij * val; }
-              } else {
-                const T c = T(2) * wij * os * base;          // symmetric pair (i,j),(j,i)
-                if constexpr (KEEP) {
-#pragma unroll
-                  for (int k = 0; k < DCAP; ++k) g[k] += c * df2[k];
-                } else if constexpr (!SPLINE) {
-#pragma unroll
-                  for (int k = 0; k < GH; ++k) {
-                    const T df = k0 + k < d ? uir[k0 + k] - ujc[k0 + k] : T(0);
-                    g[k] += c * df * df;
-                  }
-                }
-                if (first) g_os += T(2) * wij * val;
-              }
-            }
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < GH; ++k) {
-      const double s = wave_sum((double)g[k]);
-      if (lane == 0) red[wave * GP + k0 + k] = s;
-    }
-  }
-  }
-
-  // ---- noise / outputscale sums, then the reduction across the 4 waves
-  {
-    double s = wave_sum((double)g_noise);
-    if (lane == 0) red[wave * GP + MAX_DIM] = s;
-    s = wave_sum((double)g_os);
-    if (lane == 0) red[wave * GP + MAX_DIM + 1] = s;
-  }
-  __syncthreads();
-  double *out = partials + (((int64_t)lat * m + ib) * m + jb) * GP;
-  if (tid < GP) {
-    const bool live = tid < DCAP || tid >= MAX_DIM;
-    out[tid] = live ? red[tid] + red[GP + tid] + red[2 * GP + tid] + red[3 * GP + tid] : 0.0;
-  }
+  tile_mainloop<T, false, true>(acc, Wl + (int64_t)ib * NB, ldw, Wl + (int64_t)jb * NB, ldw, (int)(n_pad - (int64_t)jb * NB), smem);
+  // the epilogue body is textually included, not called: as an (always inlined) function it cost k_kinv_grad<float, 8>, which
+  // sits at exactly 128 registers, 24 bytes of scratch per lane
+  const int tid = threadIdx.x;
+  constexpr bool live = true;
+#include "kinv_epilogue.inc"
 }
+
+// The same on the bf16 matrix cores (fp32 only; bf3_engine.hpp): a workgroup of 512 threads takes the macro tile
+// (ib, ib + 1) x jb of K^-1 = W^T W from the k8-ordered planes of W (`Wp`, written by k_split_w; per latent
+// b3_elems(n_pad, n_pad) 16-bit elements), then each half of 256 threads runs the gradient epilogue on its own tile.
+// Order: longest K range first (jb ascending), latent fastest; macro tiles of column jb: ib = 0, 2, .. <= jb.
+// number of macro tiles in block columns < j:  j even: (j/2)^2 + j/2,  j odd: ((j+1)/2)^2
+__host__ __device__ inline int kinv_macro_before(int j) { const int a = j >> 1; return (j & 1) ? (a + 1) * (a + 1) : a * a + a; }
+template <int DCAP, bool SPLINE = false>
+__global__ __launch_bounds__(B3_NT, 2) void k_kinv_grad_bf3(int kind, int64_t n_pad, const float *__restrict__ alpha, const float *__restrict__ X, int n,
+                                                            int d, const float *__restrict__ ell, const float *__restrict__ oscale, float *Kinv,
+                                                            int64_t ldk, int64_t strideK, float *kinv_diag, double *__restrict__ partials, int nlat,
+                                                            int plain, const unsigned short *__restrict__ Wp) {
+  __shared__ __align__(16) unsigned char lds[B3_LDS_BYTES];
+  static_assert(2 * tile_smem_elems<float>() * sizeof(float) <= B3_LDS_BYTES, "two epilogue staging areas");
+  const int m = (int)(n_pad / NB);
+  const int w = blockIdx.x, lat = w % nlat, t = w / nlat;
+  int jb = (int)(2.0f * sqrtf((float)t));
+  if (jb >= m) jb = m - 1;
+  while (jb + 1 < m && kinv_macro_before(jb + 1) <= t) ++jb;
+  while (kinv_macro_before(jb) > t) --jb;
+  const int ibm = 2 * (t - kinv_macro_before(jb));
+  Acc<float> acc0, acc1;
+  acc0.zero();
+  acc1.zero();
+  const unsigned short *Pl = Wp + (int64_t)lat * b3_elems(n_pad, n_pad) + b3_index((int64_t)jb * NB, 0, 0, n_pad);
+  b3_mainloop(acc0, acc1, Pl + (int64_t)ibm * NB * 8, Pl + (int64_t)jb * NB * 8, n_pad, (int)(n_pad - (int64_t)jb * NB), lds);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc0.v[a][b] += acc1.v[a][b];
+  const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  const int ib = ibm + half;
+  kinv_tile_epilogue<float, DCAP, SPLINE>(acc0, reinterpret_cast<float *>(lds) + half * tile_smem_elems<float>(), (int)threadIdx.x & 255, ib <= jb, kind,
+                                          ib, jb, lat, m, n_pad, alpha, X, n, d, ell, oscale, Kinv, ldk, strideK, kinv_diag, partials, plain);
+}
+
 
 // grad[lat][k] = 1/2 * sum over upper tiles of partials, with the 1/ell_k factor for lengthscales.
 // grid (q), 1024 threads = 30 groups of GP = 34 slots; every group walks its tiles with 4 independent
@@ -496,7 +348,7 @@ int grad_tiles_impl(int kind, const T *A, int64_t n_pad, int64_t lda, int64_t st
   PLMC_REQUIRE(d > 0 && d <= MAX_DIM && q > 0, "need 0<d<=plmc_max_dim(), q>0");
   hipStream_t st = (hipStream_t)stream;
   const int m = (int)(n_pad / NB);
-  const int64_t strideV = plmc_vd_blocks(n_pad, lda) * (int64_t)NB * NB;
+  const int64_t strideV = plmc_vd_blocks_for(n_pad, lda, (int)sizeof(T)) * (int64_t)NB * NB;
   const T *Kd = Vd + strideV - (int64_t)m * NB * NB;                  // last m blocks of the scratch: diagonal K^-1 tiles
   double *part = reinterpret_cast<double *>(partials);
   const dim3 grid(q * (m * (m + 1) / 2)), block(NTHREADS);
@@ -512,34 +364,22 @@ int grad_tiles_impl(int kind, const T *A, int64_t n_pad, int64_t lda, int64_t st
   }
 #undef PLMC_LAUNCH_GT
   {
-    ProfScope ps(PK_REDUCE, st, 0.0, (double)plmc_grad_scratch_bytes(n_pad, q) / 2);
+    ProfScope ps(PK_REDUCE, st, 0.0, (double)m * m * q * GP * sizeof(double) / 2);
     hipLaunchKernelGGL(k_reduce_grad<T>, dim3(q), dim3(RED_NT), 0, st, part, m, d, ell, grad);
   }
   return launch_status(__func__);
 }
 
-// Three-plane bf16 split of the inverse factor for the BF3 gradient kernel: W (fp32, lower block triangle: block
-// (lb, cb) with cb <= lb) -> Wp[latent][plane][n_pad][n_pad].  grid (m, m, q), one 128 x 128 block per workgroup, eight
-// elements per thread and pass (two 16-byte loads, three 16-byte stores); HBM-bound.
+// Three-plane bf16 split of the inverse factor for the bf16-engine gradient kernel: W (fp32, lower block triangle: block
+// (lb, cb) with cb <= lb) -> k8-ordered planes Wp[latent][k / 8][plane][n_pad columns][k % 8] (bf3_engine.hpp).
+// grid (m, m, q), one 128 x 128 block per workgroup; HBM-bound (4 bytes read, 6 written per element).
 __global__ __launch_bounds__(NTHREADS) void k_split_w(const float *__restrict__ W, int64_t n_pad, int64_t ldw, int64_t strideW,
                                                       unsigned short *__restrict__ Wp) {
   const int cb = blockIdx.x, lb = blockIdx.y, lat = blockIdx.z;
   if (cb > lb) return;
-  const float *src = W + (int64_t)lat * strideW + (int64_t)lb * NB * ldw + (int64_t)cb * NB;
-  unsigned short *dst = Wp + (int64_t)lat * 3 * n_pad * n_pad + (int64_t)lb * NB * n_pad + (int64_t)cb * NB;
-  const int64_t ps = n_pad * n_pad;
-  for (int c = threadIdx.x; c < NB * (NB / 8); c += NTHREADS) {
-    const int r = c >> 4, col = (c & 15) * 8;
-    const float4 v0 = *reinterpret_cast<const float4 *>(src + (int64_t)r * ldw + col);
-    const float4 v1 = *reinterpret_cast<const float4 *>(src + (int64_t)r * ldw + col + 4);
-    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    bf3_s16x8 h, m, l;
-    bf3_split8(x, h, m, l);
-    unsigned short *o = dst + (int64_t)r * n_pad + col;
-    *reinterpret_cast<bf3_s16x8 *>(o) = h;
-    *reinterpret_cast<bf3_s16x8 *>(o + ps) = m;
-    *reinterpret_cast<bf3_s16x8 *>(o + 2 * ps) = l;
-  }
+  b3_split_block<false>(W + (int64_t)lat * strideW + (int64_t)lb * NB * ldw + (int64_t)cb * NB, ldw,
+                        Wp + (int64_t)lat * b3_elems(n_pad, n_pad) + b3_index((int64_t)lb * NB, 0, (int64_t)cb * NB, n_pad), n_pad, nullptr, 0,
+                        threadIdx.x);
 }
 
 template <typename T>
@@ -562,30 +402,34 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
   const int plain = knobs().kinv_order;
   const dim3 grid = plain >= 4 ? dim3(q * (m * (m + 1) / 2)) : plain ? dim3(m, m, q) : dim3(xcd_tri_grid(m, q)), block(NTHREADS);
   double *part = reinterpret_cast<double *>(partials);
-  // opt-in (PLMC_BF16X3, fp32 only): split W into bf16 planes behind the partials, run the product on the bf16 cores
-  const unsigned short *Wp = nullptr;
-  bool bf3 = false;
+  const double np = (double)n_pad;
+  // fp32 products on the bf16 matrix cores (PLMC_BF16X3, the fp32 default; bf3_engine.hpp): split W into k8-ordered bf16
+  // planes behind the partials, then the macro-tile kernel
+  bool done = false;
   if constexpr (sizeof(T) == 4) {
     if (knobs().bf16x3) {
       unsigned short *wp = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(partials) + (int64_t)m * m * q * GP * (int64_t)sizeof(double));
-      ProfScope ps(PK_SPLIT, st, 0.0, (double)q * n_pad * n_pad / 2 * (4 + 6));
-      hipLaunchKernelGGL(k_split_w, dim3(m, m, q), dim3(NTHREADS), 0, st, (const float *)W, n_pad, ldw, strideW, wp);
-      Wp = wp;
-      bf3 = true;
+      {
+        ProfScope ps(PK_SPLIT, st, 0.0, (double)q * np * np / 2 * (4 + 6));
+        hipLaunchKernelGGL(k_split_w, dim3(m, m, q), dim3(NTHREADS), 0, st, (const float *)W, n_pad, ldw, strideW, wp);
+      }
+      const dim3 gridb(q * kinv_macro_before(m));
+#define PLMC_LAUNCH_KB(DC, SP) \
+  hipLaunchKernelGGL((k_kinv_grad_bf3<DC, SP>), gridb, dim3(B3_NT), 0, st, kind, n_pad, alpha, X, n, d, ell, oscale, Kinv, ldk, strideK, kinv_diag, \
+                     part, q, plain, (const unsigned short *)wp)
+      ProfScope ps(PK_KINV_GRAD, st, q * np * np * np / 3.0, q * (np * np / 2) * sizeof(T));
+      if (d <= 4) PLMC_LAUNCH_KB(4, false);
+      else if (d <= 8) PLMC_LAUNCH_KB(8, false);
+      else if (d <= 16) { if (kind == K_SPLINE) PLMC_LAUNCH_KB(16, true); else PLMC_LAUNCH_KB(16, false); }
+      else { if (kind == K_SPLINE) PLMC_LAUNCH_KB(32, true); else PLMC_LAUNCH_KB(32, false); }
+#undef PLMC_LAUNCH_KB
+      done = true;
     }
   }
-#define PLMC_LAUNCH_KG2(DC, SP, B3)                                                                                  \
-  hipLaunchKernelGGL((k_kinv_grad<T, DC, SP, B3>), grid, block, 0, st, kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, \
-                     oscale, Kinv, ldk, strideK, kinv_diag, part, q, plain, Wp)
-#define PLMC_LAUNCH_KG(DC, SP)                                                                                      \
-  do {                                                                                                               \
-    if constexpr (sizeof(T) == 4) {                                                                                  \
-      if (bf3) { PLMC_LAUNCH_KG2(DC, SP, true); break; }                                                              \
-    }                                                                                                                \
-    PLMC_LAUNCH_KG2(DC, SP, false);                                                                                  \
-  } while (0)
-  {
-    const double np = (double)n_pad;
+#define PLMC_LAUNCH_KG(DC, SP)                                                                                       \
+  hipLaunchKernelGGL((k_kinv_grad<T, DC, SP>), grid, block, 0, st, kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, \
+                     oscale, Kinv, ldk, strideK, kinv_diag, part, q, plain)
+  if (!done) {
     ProfScope ps(PK_KINV_GRAD, st, q * np * np * np / 3.0, q * (np * np / 2) * sizeof(T));
     if (d <= 4) PLMC_LAUNCH_KG(4, false);
     else if (d <= 8) PLMC_LAUNCH_KG(8, false);
@@ -593,9 +437,8 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
     else { if (kind == K_SPLINE) PLMC_LAUNCH_KG(32, true); else PLMC_LAUNCH_KG(32, false); }
   }
 #undef PLMC_LAUNCH_KG
-#undef PLMC_LAUNCH_KG2
   {
-    ProfScope ps(PK_REDUCE, st, 0.0, (double)plmc_grad_scratch_bytes(n_pad, q) / 2);
+    ProfScope ps(PK_REDUCE, st, 0.0, (double)m * m * q * GP * sizeof(double) / 2);
     hipLaunchKernelGGL(k_reduce_grad<T>, dim3(q), dim3(RED_NT), 0, st, part, m, d, ell, grad);
   }
   return launch_status(__func__);
@@ -614,11 +457,13 @@ int plmc_grad_tiles_f64(int kind, const double *A, int64_t n_pad, int64_t lda, i
                         void *partials, int q, void *stream) {
   return plmc::grad_tiles_impl<double>(kind, A, n_pad, lda, strideA, Vd, alpha, X, n, d, ell, oscale, grad, kinv_diag, partials, q, stream);
 }
-int64_t plmc_grad_scratch_bytes(int64_t n_pad, int q) {
+// per-tile partial sums + (4-byte elements) the bf16 planes of W for the bf16 engine; independent of the knobs
+int64_t plmc_grad_scratch_bytes_for(int64_t n_pad, int q, int elem_bytes) {
   int64_t m = n_pad / plmc::NB;
-  const int64_t planes = plmc::knobs().bf16x3 ? (int64_t)q * 3 * n_pad * n_pad * 2 : 0;   // bf16 planes of W (opt-in, fp32)
+  const int64_t planes = elem_bytes == 4 ? (int64_t)q * plmc::b3_elems(n_pad, n_pad) * 2 : 0;
   return m * m * (int64_t)q * plmc::GP * (int64_t)sizeof(double) + planes;
 }
+int64_t plmc_grad_scratch_bytes(int64_t n_pad, int q) { return plmc_grad_scratch_bytes_for(n_pad, q, 4); }
 int plmc_kinv_grad_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW, const float *alpha,
                        const float *X, int n, int d, const float *ell, const float *oscale, double *grad,
                        float *Kinv, int64_t ldk, int64_t strideK, float *kinv_diag, void *partials, int q,

@@ -34,10 +34,11 @@ class Workspace:
         if (self.lda // self.NB) % 2 == 0:
             self.lda += self.NB          # odd number of blocks per row: keeps the row stride off a power of two
         self.strideA = self.n_pad * self.lda
-        self.Vd = torch.empty(q, int(L.cdll.plmc_vd_blocks(self.n_pad, self.lda)), self.NB, self.NB, dtype=dtype, device=device)
+        esz = torch.empty((), dtype=dtype).element_size()
+        # scratch sizes depend on (n_pad, lda, element size) only -- never on a dev knob (include/plmc.h, version 3)
+        self.Vd = torch.empty(q, int(L.cdll.plmc_vd_blocks_for(self.n_pad, self.lda, esz)), self.NB, self.NB, dtype=dtype, device=device)
         self.m = self.n_pad // self.NB
         self.A = torch.empty(q, self.n_pad, self.lda, dtype=dtype, device=device)
-        
         self.logdet = torch.empty(q, dtype=torch.float64, device=device)
         self.quad = torch.empty(q, dtype=torch.float64, device=device)
         self.info = torch.empty(q, dtype=torch.int32, device=device)
@@ -48,7 +49,7 @@ class Workspace:
             self.W = self.A[:, :, self.wcol0:self.wcol0 + self.n_pad]
             self.ldw, self.strideW = self.lda, self.strideA
             self.alpha = torch.empty(q, self.n_pad, dtype=dtype, device=device)
-            nbytes = int(L.cdll.plmc_grad_scratch_bytes(self.n_pad, q))
+            nbytes = int(L.cdll.plmc_grad_scratch_bytes_for(self.n_pad, q, esz))
             self.partials = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
 
 

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PLMC_LIB: dev override (a variant build of the same library, tools/wb_race_probe.py); never a fallback
 LIB_PATH = os.environ.get("PLMC_LIB") or os.path.join(_HERE, "libplmc_hip.so")
 
+ABI_VERSION = 3          # include/plmc.h: plmc_version()
 KIND = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3, "spline": 4}
 
 _c = ctypes
@@ -45,10 +46,12 @@ _PLAIN = {
     "plmc_block": ([], _I),
     "plmc_pad": ([_L], _L),
     "plmc_vd_blocks": ([_L, _L], _L),
+    "plmc_vd_blocks_for": ([_L, _L, _I], _L),
     "plmc_max_dim": ([], _I),
     "plmc_qr_max": ([], _I),
     "plmc_last_error": ([], _c.c_char_p),
     "plmc_grad_scratch_bytes": ([_L, _I], _L),
+    "plmc_grad_scratch_bytes_for": ([_L, _I, _I], _L),
     "plmc_lmc_grad_len": ([_I, _I, _I], _L),
     "plmc_lmc_grad_scratch_bytes": ([_L, _I, _I, _I], _L),
     "plmc_prof_enable": ([_I], _I),
@@ -141,6 +144,9 @@ class _Lib:
             for suf in ("_f32", "_f64"):
                 fn = getattr(self.cdll, base + suf)
                 fn.argtypes, fn.restype = args, _I
+        if self.cdll.plmc_version() != ABI_VERSION:
+            raise RuntimeError("projectedlmc: %s is ABI version %d, this package needs %d (the scratch-size contract of "
+                               "plmc_potrf_* / plmc_kinv_grad_* differs) -- rebuild it" % (LIB_PATH, self.cdll.plmc_version(), ABI_VERSION))
 
     def call(self, base, dtype, *args):
         """Typed entry point.  The library picks its helper streams / ordering events by the CURRENT HIP device, so the
