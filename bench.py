@@ -29,7 +29,14 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "projected-lmc_amd")]
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}     # MI355X_MICROARCH.md chip table (dense matrix peaks)
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6, "bf16": 2500.0}     # MI355X_MICROARCH.md chip table (dense matrix peaks)
+SPLIT_PRODUCTS = 6          # bf16 plane products per fp32 product in the split engine (csrc/bf3_engine.hpp)
+ARITHMETIC = {
+    True: "fp32 storage, results and accumulation; the bulk products (tail / head updates of the sweep, K^-1 = W^T W) on "
+          "v_mfma_f32_16x16x32_bf16 from operands split exactly into three bf16 planes (x = hi + mid + lo), six plane products "
+          "into two fp32 accumulator levels (error vs fp64 0.3-0.4 x the fp32 MFMA chain's, profiles/r03_split_numerics.txt); "
+          "chain, group panel and look-ahead updates on v_mfma_f32_16x16x4_f32",
+    False: "fp32 storage and arithmetic: every product on v_mfma_f32_16x16x4_f32 (PLMC_BF16X3=0)"}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -182,7 +189,7 @@ def main():
     ap.add_argument("--variant", default="PLMC_fast", choices=["PLMC_fast", "PLMC"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--no-options", action="store_true", help="skip the untimed-for-the-headline run of the opt-in bf16x3 gradient kernel")
+    ap.add_argument("--no-options", action="store_true", help="skip the run with PLMC_BF16X3=0 (fp32 MFMA everywhere) that is reported beside the headline")
     ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic live (two rocprofv3 --pmc child runs) "
                                                       "when no profile of this build is committed")
     args = ap.parse_args()
@@ -327,14 +334,14 @@ def main():
             fence()
             iso = _hip.prof_collect()
         _hip.prof_enable(False)
-    # Opt-in arithmetic, reported BESIDE the headline and never as it: PLMC_BF16X3=1 runs the W^T W products of the
-    # K^-1 + gradient kernel on the bf16 matrix cores from three-plane split fp32 operands (six plane products, fp32
-    # accumulate).  Same step, same K; its accuracy is checked at the same checkpoint states.
+    # The same steps with PLMC_BF16X3=0 -- every product on the fp32 matrix instruction -- reported BESIDE the headline with its
+    # own accuracy checks at the same checkpoint states (the split engine is the default only while its
+    # errors are at or below this path's).
+    split_on = os.environ.get("PLMC_BF16X3", "1") != "0"
     option = None
-    if world == 1 and not args.no_options:
+    if world == 1 and not args.no_options and split_on:
         try:
-            with _hip.knob("PLMC_BF16X3", "1"):
-                _engine.free_workspaces()
+            with _hip.knob("PLMC_BF16X3", "0"):
                 for i in range(2):
                     step()
                 fence()
@@ -345,13 +352,11 @@ def main():
                 el = time.perf_counter() - t0
                 option = {"ms_per_step": 1e3 * el / args.steps, "iters_per_sec": args.steps / el}
                 if do_checks and st5 is not None:
-                    gpu_checkpoint("after %d optimiser steps [bf16x3 option]" % n_check, st5, sorted({0, q - 1}))
+                    gpu_checkpoint("after %d optimiser steps [fp32 mfma]" % n_check, st5, sorted({0, q - 1}))
                     model.train()
-        except Exception as exc:                            # the option must never cost the headline line
+        except Exception as exc:                            # the comparison run must never cost the headline line
             option = {"error": "%s: %s" % (type(exc).__name__, exc)}
-            checkpoints[:] = [c for c in checkpoints if not c[0].endswith("[bf16x3 option]")]
-        finally:
-            _engine.free_workspaces()
+            checkpoints[:] = [c for c in checkpoints if not c[0].endswith("[fp32 mfma]")]
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -362,7 +367,8 @@ def main():
         res = {
             "metric": "MLL+grad iters/sec, n=8192 16-task LMC", "value": its, "unit": "iters/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "arithmetic": ARITHMETIC[split_on],
+            "data": "synthetic",
             "config": {"workload": "C3: ProjectedGPModel+ProjectedLMCmll exact training step (%s), n=%d d=%d p=%d q=%d "
                                    "Matern-5/2 fp32; latents sharded q/N per GPU" % (args.variant, n, d, p, q),
                        "n_points": n, "n_dim": d, "n_tasks": p, "n_latents": q, "parallelism": "latent-shard x%d" % world},
@@ -378,12 +384,16 @@ def main():
             dom = max(mf, key=lambda k: mf[k]["ms"])
             s = mf[dom]
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
-            peak = MFMA_PEAK_TFLOPS["f32"]
-            try:
-                peak_meas = _hip.mfma_rate(torch.float32, dev)    # bare v_mfma_f32_16x16x4_f32 stream on this device, now
+            # the three bracketed classes are exactly the launches the split engine carries: their peak is the dense bf16 peak
+            # divided by the six plane products one fp32 product costs (fp32-equivalent TFLOP/s); with PLMC_BF16X3=0 the fp32 peak
+            peak = MFMA_PEAK_TFLOPS["bf16"] / SPLIT_PRODUCTS if split_on else MFMA_PEAK_TFLOPS["f32"]
+            try:                                                  # bare instruction stream on this device, now
+                peak_meas = (_hip.mfma_rate("bf16", dev) / SPLIT_PRODUCTS) if split_on else _hip.mfma_rate(torch.float32, dev)
             except Exception:
                 peak_meas = None
             res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "peak_note": ("fp32-equivalent: dense bf16 MFMA peak %.0f / %d plane products" % (MFMA_PEAK_TFLOPS["bf16"], SPLIT_PRODUCTS))
+                               if split_on else "dense fp32 MFMA peak",
                                "frac": ach / peak, "traffic": None, "peak_measured": peak_meas,
                                "frac_of_measured_peak": (ach / peak_meas) if peak_meas else None,
                                "avg_launch_ms": s["ms"] / s["launches"], "launches": s["launches"],
@@ -397,8 +407,9 @@ def main():
             # HBM bytes per launch from the PMC counters.  They cannot be read from inside the process: they come from
             # rocprofv3 --pmc passes of this same command -- the committed ones if they were measured on THIS build
             # (build key over the library sources), else (--pmc) two child runs now, else null.
-            kname = {"k_trail": "k_update<float, 0, 4>", "k_trail_head": "k_update<float, 2, 4>",
-                     "k_kinv_grad": "k_kinv_grad<float, 8, false, false>", "k_gpanel": "k_gpanel_rows<float>"}.get(dom, dom + "<float>")
+            kname = ({"k_trail": "k_update_bf3<0>", "k_trail_head": "k_update_bf3<3>", "k_kinv_grad": "k_kinv_grad_bf3<8, false>"} if split_on else
+                     {"k_trail": "k_update<float, 0, 4>", "k_trail_head": "k_update<float, 3, 4>",
+                      "k_kinv_grad": "k_kinv_grad<float, 8, false>"}).get(dom, dom + "<float>")
             if world == 1:
                 tr, src = committed_traffic(kname)
                 if tr is None and args.pmc:
@@ -421,11 +432,14 @@ def main():
             q_loc = len(range(rank, q, world))
             chol_ms = sweep["ms"] / args.steps
             f_sweep = 2.0 * q_loc * n ** 3 / 3
+            p32 = MFMA_PEAK_TFLOPS["f32"]
             res["cholesky_gemm"] = {"what": "factor U and inverse factor W in one sweep, 2 q n^3 / 3 flop",
                                     "tflops": f_sweep / (chol_ms * 1e-3) / 1e12, "ms_per_step": chol_ms,
-                                    "frac_of_mfma_peak": f_sweep / (chol_ms * 1e-3) / 1e12 / peak}
+                                    "frac_of_fp32_mfma_peak": f_sweep / (chol_ms * 1e-3) / 1e12 / p32}
             res["step_dense"] = {"tflops": q_loc * n ** 3 / (elapsed / args.steps) / 1e12,
-                                 "frac_of_mfma_peak": q_loc * n ** 3 / (elapsed / args.steps) / 1e12 / peak}
+                                 "frac_of_fp32_mfma_peak": q_loc * n ** 3 / (elapsed / args.steps) / 1e12 / p32,
+                                 "note": "q n^3 flop per step over the step time, against the fp32 matrix peak %.1f TF (the step may "
+                                         "exceed it: its bulk products run on the bf16 matrix cores)" % p32}
         note("%.2f ms/step on %d GPU(s)" % (1e3 * elapsed / args.steps, world))
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle on %d host cores (bounded sample: 4 of %d latents) ..." % (host_cores(), q))
@@ -436,11 +450,11 @@ def main():
             checks = []
             opt_checks, memo = [], {}
             for label, j, e, z, yt, lp_gpu, g_gpu in checkpoints:
-                key = (j, label.replace(" [bf16x3 option]", ""))
+                key = (j, label.replace(" [fp32 mfma]", ""))
                 if key not in memo:
                     memo[key] = oracle_latent(X, e, z, yt)
                 lp_cpu, g_cpu = memo[key]
-                (opt_checks if label.endswith("[bf16x3 option]") else checks).append(
+                (opt_checks if label.endswith("[fp32 mfma]") else checks).append(
                     {"where": "latent %d, %s" % (j, label), "logp_hip_f32": lp_gpu, "logp_oracle_f64": lp_cpu,
                      "loglik_rel_err": abs(lp_gpu - lp_cpu) / abs(lp_cpu),
                      "grad_rel_err": float((g_gpu - g_cpu).norm() / g_cpu.norm()),
@@ -457,10 +471,8 @@ def main():
                                     "checkpoints in loglik_rel_err / grad_rel_err" % n)
         res["first_loss"] = first_loss
         if option is not None:
-            option["what"] = ("NOT the headline: the same %d steps with PLMC_BF16X3=1 -- the W^T W products of the K^-1 + gradient "
-                              "kernel on the bf16 matrix cores from three-plane split fp32 operands (six plane products, fp32 "
-                              "accumulate); everything else as in the headline run" % args.steps)
-            res["bf16x3_option"] = option
+            option["what"] = ("NOT the headline: the same %d steps with PLMC_BF16X3=0 -- " % args.steps) + ARITHMETIC[False]
+            res["fp32_mfma_option"] = option
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -293,14 +293,14 @@ int plmc_qr_small_f64(const double *A, int m, int n, int64_t lda, double *Q, int
  * of the bulk fp32 products (plmc_kinv_grad_f32 and the depth-(128 G) tail / head updates inside plmc_potrf_f32): 1 = split
  * operands on the bf16 matrix cores (bf3_engine.hpp), 0 = v_mfma_f32_16x16x4_f32.  Buffer sizes do not depend on any knob.
  * plmc_prof_mfma_rate: dense MFMA rate (TFLOP/s) of the current device measured with a bare instruction stream
- * (v_mfma_f32_16x16x4_f32 or _f64_16x16x4_f64, 4 waves per SIMD, no memory traffic); synchronous; `sink` = caller-owned
+ * (v_mfma_f32_16x16x4_f32, _f64_16x16x4_f64 or v_mfma_f32_16x16x32_bf16, 4 waves per SIMD, no memory traffic); synchronous; `sink` = caller-owned
  * device scratch of at least 4 * CUs * 256 * sizeof(element) bytes.
  */
 int         plmc_prof_enable(int on);         /* returns the previous setting */
 int         plmc_prof_kernels(void);
 const char *plmc_prof_name(int id);
 int         plmc_prof_collect(double *ms, int64_t *launches, double *flops, double *bytes);
-int         plmc_prof_mfma_rate(int is_f64, void *sink, int64_t sink_bytes, double *tflops);
+int         plmc_prof_mfma_rate(int kind, void *sink, int64_t sink_bytes, double *tflops);   /* kind: 0 f32, 1 f64, 2 bf16 (16x16x32) */
 int         plmc_dev_reload_knobs(void);
 
 #ifdef __cplusplus

@@ -39,7 +39,7 @@ static void load_knobs() {
   g_knobs.serial = getenv("PLMC_SERIAL") && atoi(getenv("PLMC_SERIAL")) != 0;
   g_knobs.kinv_order = o ? atoi(o) : 4;
   g_knobs.bulk_lds = getenv("PLMC_BULK_LDS") ? atoi(getenv("PLMC_BULK_LDS")) : -1;
-  g_knobs.bf16x3 = getenv("PLMC_BF16X3") && atoi(getenv("PLMC_BF16X3")) != 0;
+  g_knobs.bf16x3 = !getenv("PLMC_BF16X3") || atoi(getenv("PLMC_BF16X3")) != 0;     // default ON (fp32 entry points only)
   g_knobs_loaded = true;
 }
 const Knobs &knobs() {
@@ -95,7 +95,31 @@ __global__ __launch_bounds__(NTHREADS) void k_mfma_rate(T *sink, int iters) {
   sink[(size_t)blockIdx.x * NTHREADS + threadIdx.x] = s;
 }
 
-template <typename T> static int mfma_rate_impl(void *sink, int64_t sink_bytes, double *tflops) {
+// the same for v_mfma_f32_16x16x32_bf16 (the split engine's instruction), fp32 accumulators
+typedef __bf16 rate_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(NTHREADS) void k_mfma_rate_bf16(float *sink, int iters) {
+  f32x4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+  rate_bf16x8 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a[i][j] = (__bf16)(1.0f + 0.01f * (float)((threadIdx.x + j) & 7) + (float)i); b[i][j] = (__bf16)(0.5f - 0.01f * (float)(i + j)); }
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i >> 2], b[i & 3], acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  sink[(size_t)blockIdx.x * NTHREADS + threadIdx.x] = s;
+}
+
+template <typename T, bool BF16 = false> static int mfma_rate_impl(void *sink, int64_t sink_bytes, double *tflops) {
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail("plmc_prof_mfma_rate", "no device");
@@ -106,11 +130,12 @@ template <typename T> static int mfma_rate_impl(void *sink, int64_t sink_bytes, 
   double best = 0.0;
   for (int rep = 0; rep < 3; ++rep) {                 // first repetition warms the clocks up
     (void)hipEventRecord(e0, nullptr);
-    hipLaunchKernelGGL(k_mfma_rate<T>, dim3(grid), dim3(NTHREADS), 0, nullptr, (T *)sink, iters);
+    if (BF16) hipLaunchKernelGGL(k_mfma_rate_bf16, dim3(grid), dim3(NTHREADS), 0, nullptr, (float *)sink, iters);
+    else hipLaunchKernelGGL(k_mfma_rate<T>, dim3(grid), dim3(NTHREADS), 0, nullptr, (T *)sink, iters);
     (void)hipEventRecord(e1, nullptr);
     float ms = 0.f;
     if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) break;
-    const double fl = (double)grid * (NTHREADS / 64) * (double)iters * 16.0 * 2.0 * 16 * 16 * 4;
+    const double fl = (double)grid * (NTHREADS / 64) * (double)iters * 16.0 * 2.0 * 16 * 16 * (BF16 ? 32 : 4);
     if (ms > 0.f && fl / (ms * 1e-3) / 1e12 > best) best = fl / (ms * 1e-3) / 1e12;
   }
   (void)hipEventDestroy(e0);
@@ -144,8 +169,9 @@ int plmc_prof_enable(int on) {
   plmc::g_prof_mask = on == 0 ? 0u : (on == 1 ? all : ((unsigned)on >> 1) & all);
   return prev == 0 ? 0 : (prev == all ? 1 : (int)(prev << 1));
 }
-int plmc_prof_mfma_rate(int is_f64, void *sink, int64_t sink_bytes, double *tflops) {
-  return is_f64 ? plmc::mfma_rate_impl<double>(sink, sink_bytes, tflops) : plmc::mfma_rate_impl<float>(sink, sink_bytes, tflops);
+int plmc_prof_mfma_rate(int kind, void *sink, int64_t sink_bytes, double *tflops) {      // kind: 0 f32, 1 f64, 2 bf16
+  if (kind == 2) return plmc::mfma_rate_impl<float, true>(sink, sink_bytes, tflops);
+  return kind ? plmc::mfma_rate_impl<double>(sink, sink_bytes, tflops) : plmc::mfma_rate_impl<float>(sink, sink_bytes, tflops);
 }
 int plmc_dev_reload_knobs(void) { plmc::load_knobs(); return 0; }
 int plmc_prof_kernels(void) { return plmc::PK_COUNT; }

@@ -44,13 +44,15 @@ struct ProfScope {
 };
 
 // Dev knobs (environment variables), read ONCE per process on first use; plmc_dev_reload_knobs() re-reads them (the
-// tests and bench.py change a knob and reload).  None of them changes results, only schedules.
+// tests and bench.py change a knob and reload).  They change schedules; PLMC_GRP also changes the depth of the updates (and
+// with it the rounding), PLMC_BF16X3 selects the arithmetic of the bulk fp32 products.
 struct Knobs {
   double half_tiles;   // PLMC_HALF_TILES: 0 never, 1 always, N > 1 = tile-count threshold (default 640)
   int grp;             // PLMC_GRP: fixed group size of the sweep (default 0 = 8)
   bool serial;         // PLMC_SERIAL: one stream, no look-ahead
   int bulk_lds;        // PLMC_BULK_LDS: extra dynamic LDS bytes per bulk workgroup (caps bulk occupancy); -1 = default by q
-  bool bf16x3;         // PLMC_BF16X3=1: fp32 K^-1 products on the bf16 matrix cores from three-plane split operands (opt-in)
+  bool bf16x3;         // PLMC_BF16X3 (default 1): bulk fp32 products (tail / head updates, K^-1) on the bf16 matrix cores from three-plane
+                       // split operands, two accumulator levels (bf3_engine.hpp); 0: v_mfma_f32_16x16x4_f32 everywhere
   int kinv_order;      // PLMC_KINV_ORDER: tile order of the gradient kernel (0 XCD-dealt, 1 grid, 4 longest first, 5 = 4 + general epilogue)
 };
 const Knobs &knobs();

@@ -109,14 +109,16 @@ class knob:
 
 
 def mfma_rate(dtype=torch.float32, device=None):
-    """Measured dense MFMA rate (TFLOP/s) of the device: bare instruction stream, no memory traffic."""
+    """Measured dense MFMA rate (TFLOP/s) of the device: bare instruction stream, no memory traffic.
+    dtype: torch.float32 / torch.float64 (v_mfma_*_16x16x4) or "bf16" (v_mfma_f32_16x16x32_bf16, the split engine's)."""
     L = lib().cdll
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-    sink = torch.empty(4 * 1024 * 256, dtype=dtype, device=dev)
+    kind = 2 if dtype == "bf16" else int(dtype == torch.float64)
+    sink = torch.empty(4 * 1024 * 256, dtype=torch.float32 if kind == 2 else dtype, device=dev)
     out = _c.c_double(0.0)
     with torch.cuda.device(dev):
         torch.cuda.synchronize(dev)
-        rc = L.plmc_prof_mfma_rate(int(dtype == torch.float64), ptr(sink), sink.numel() * sink.element_size(), _c.byref(out))
+        rc = L.plmc_prof_mfma_rate(kind, ptr(sink), sink.numel() * sink.element_size(), _c.byref(out))
     if rc != 0:
         raise RuntimeError("plmc_prof_mfma_rate failed: %s" % L.plmc_last_error().decode())
     return out.value
