@@ -53,6 +53,7 @@ struct Knobs {
   int bulk_lds;        // PLMC_BULK_LDS: extra dynamic LDS bytes per bulk workgroup (caps bulk occupancy); -1 = default by q
   bool bf16x3;         // PLMC_BF16X3 (default 1): bulk fp32 products (tail / head updates, K^-1) on the bf16 matrix cores from three-plane
                        // split operands, two accumulator levels (bf3_engine.hpp); 0: v_mfma_f32_16x16x4_f32 everywhere
+  int bulk_streams;    // PLMC_BULK_STREAMS: 2 = group panel + head rows on their own helper stream beside the tail, 1 = in front of the tail on the caller's stream
   int kinv_order;      // PLMC_KINV_ORDER: tile order of the gradient kernel (0 XCD-dealt, 1 grid, 4 longest first, 5 = 4 + general epilogue)
 };
 const Knobs &knobs();

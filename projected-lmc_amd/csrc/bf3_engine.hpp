@@ -92,26 +92,26 @@ __device__ __forceinline__ void b3_split_block(const float *__restrict__ S, int6
 }
 
 // acc0 / acc1 += the two levels of  sum_{k < K} A[k][a-columns]^T B[k][b-columns]  for this wave's 64 x 64 block.
-//   Ap: plane buffer at (k = first row of the K range, plane 0, first of the 256 A columns);  Bp: likewise, first of the
-//   128 B columns;  ld: columns of the plane buffer;  K % 64 == 0;  lds: B3_LDS_BYTES, 16-byte aligned, the kernel's ONLY
-//   __shared__ object (a second one makes hipcc drain the DMA before every fragment read).
+//   Ap: plane buffer at (k = first row of the K range, plane 0, first of the 256 A columns), lda_ columns per plane row;
+//   Bp: likewise, first of the 128 B columns, ldb_ columns;  K % 64 == 0;  lds: B3_LDS_BYTES, 16-byte aligned, the kernel's
+//   ONLY __shared__ object (a second one makes hipcc drain the DMA before every fragment read).
 // All 512 threads must call it; ends with a barrier (LDS free for the epilogue).
-__device__ __forceinline__ void b3_mainloop(Acc<float> &acc0, Acc<float> &acc1, const unsigned short *__restrict__ Ap,
-                                            const unsigned short *__restrict__ Bp, int64_t ld, int K, unsigned char *lds) {
+__device__ __forceinline__ void b3_mainloop(Acc<float> &acc0, Acc<float> &acc1, const unsigned short *__restrict__ Ap, int64_t lda_,
+                                            const unsigned short *__restrict__ Bp, int64_t ldb_, int K, unsigned char *lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave 0..7, provably uniform (DMA destinations are scalar)
   const int half = w >> 2, wm = (w >> 1) & 1, wn = w & 1;
   // ---- DMA plan of this wave: pieces i = w + 8 j of the 72 per stage.  j = 0..5: A, plane j >> 1, k-group (w >> 2) + 2 (j & 1),
   // columns 64 (w & 3) ..; j = 6..8: B, plane j - 6, k-group (w >> 1) & 3, columns 64 (w & 1) ..
-  const unsigned RS = (unsigned)(3 * ld * 16);                      // bytes per k8 row (all planes)
-  const unsigned PL = (unsigned)(ld * 16);                          // bytes per plane inside a k8 row
-  const unsigned gA0 = (unsigned)(w >> 2) * RS + (unsigned)(w & 3) * 1024u;
-  const unsigned gB0 = (unsigned)((w >> 1) & 3) * RS + (unsigned)(w & 1) * 1024u;
+  const unsigned RSA = (unsigned)(3 * lda_ * 16), RSB = (unsigned)(3 * ldb_ * 16);   // bytes per k8 row (all planes)
+  const unsigned PLA = (unsigned)(lda_ * 16), PLB = (unsigned)(ldb_ * 16);           // bytes per plane inside a k8 row
+  const unsigned gA0 = (unsigned)(w >> 2) * RSA + (unsigned)(w & 3) * 1024u;
+  const unsigned gB0 = (unsigned)((w >> 1) & 3) * RSB + (unsigned)(w & 1) * 1024u;
   const unsigned lA0 = (unsigned)(((w >> 2) * B3_AW + (w & 3) * 64) * 16);
   const unsigned lB0 = (unsigned)(3 * B3_A_PLANE + (((w >> 1) & 3) * B3_BW + (w & 1) * 64) * 16);
   const unsigned voff = (unsigned)lane * 16u;
   const char *baseA = reinterpret_cast<const char *>(Ap), *baseB = reinterpret_cast<const char *>(Bp);
-  const int64_t step = (int64_t)(B3_K / 8) * RS;
+  const int64_t stepA = (int64_t)(B3_K / 8) * RSA, stepB = (int64_t)(B3_K / 8) * RSB;
   typedef __attribute__((address_space(3))) void lds_void;
   auto issue = [&](int buf) {
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(baseA), 0, 0x7fffffff, 0x00020000);
@@ -120,12 +120,12 @@ __device__ __forceinline__ void b3_mainloop(Acc<float> &acc0, Acc<float> &acc1, 
 #pragma unroll
     for (int j = 0; j < 6; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void *)(sb + lA0 + (j >> 1) * B3_A_PLANE + (j & 1) * (2 * B3_AW * 16)), 16, voff,
-                                           gA0 + (unsigned)(j & 1) * 2u * RS + (unsigned)(j >> 1) * PL, 0, 0);
+                                           gA0 + (unsigned)(j & 1) * 2u * RSA + (unsigned)(j >> 1) * PLA, 0, 0);
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void *)(sb + lB0 + j * B3_B_PLANE), 16, voff, gB0 + (unsigned)j * PL, 0, 0);
-    baseA += step;
-    baseB += step;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void *)(sb + lB0 + j * B3_B_PLANE), 16, voff, gB0 + (unsigned)j * PLB, 0, 0);
+    baseA += stepA;
+    baseB += stepB;
   };
   // ---- fragment addresses: lane (kg = lane >> 4, fr = lane & 15) reads 16 bytes of k-group kg, row / column .. + fr
   const int kg = lane >> 4, fr = lane & 15;
@@ -174,6 +174,69 @@ __device__ __forceinline__ void b3_mainloop(Acc<float> &acc0, Acc<float> &acc1, 
     compute(1);
   }
   __syncthreads();
+}
+
+// Epilogue of one 128 x 128 half of the macro tile: tile_writeback (gemm_core.hpp) for fp32 plus, with PLANES, the FINAL
+// values of the tile also as k8-ordered bf16 planes -- the next consumer's operand, written while the tile is still in
+// LDS instead of by a separate split pass.  `Pp` = plane buffer at (k = the tile's first row, plane 0, the tile's first
+// column), `pld` its columns.  Per 64-row pass the finals go back into the staging area (for the read-modify-write modes),
+// then every thread splits 8 rows x 4 columns.  tid = threadIdx.x & 255; `live` as in tile_writeback; `planes_live`: this half
+// also writes planes (both wave-uniform per half).
+template <int MODE, bool PLANES>
+__device__ __forceinline__ void b3_writeback(const Acc<float> &acc, float *Cg, int64_t ldc, float *smem, int tid, bool live,
+                                             unsigned short *Pp = nullptr, int64_t pld = 0, bool planes_live = true) {
+  if constexpr (!PLANES) {
+    tile_writeback<float, MODE>(acc, Cg, ldc, smem, tid, live);
+  } else {
+    constexpr bool ADD = MODE == WB_ADD || MODE == WB_SUB;
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int LDW = 132, CPR = 32, NCH = 8, RSTEP = 8;       // as tile_writeback<float>: 16-byte chunks, 8 per thread and pass
+    const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int row0 = tid / CPR, col0 = (tid % CPR) * 4;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(Cg, 0, __builtin_amdgcn_readfirstlane(live ? 0x7fffffff : 0), 0x00020000);
+    const unsigned voff = (unsigned)(((int64_t)row0 * ldc + col0) * 4);
+    const unsigned rstep = (unsigned)((int64_t)RSTEP * ldc * 4);
+    f32x4 vc[NCH];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (ADD) {                                                   // the C rows of this pass, all in flight while the pass is staged
+#pragma unroll
+        for (int h = 0; h < NCH; ++h)
+          vc[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rC, voff, (unsigned)(half * 8 + h) * rstep, 0));
+      }
+      if (half) __syncthreads();                                   // plane pass of the previous half is done with the staging area
+      if (wm == half) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = mt * 16 + Traits<float>::acc_row(lane, r);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) smem[row * LDW + wn * 64 + nt * 16 + (lane & 15)] = acc.v[mt][nt][r];
+          }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        float *sp = smem + (row0 + h * RSTEP) * LDW + col0;
+        const f32x4 sv = *reinterpret_cast<const f32x4 *>(sp);
+        const f32x4 o = MODE == WB_ADD ? vc[h] + sv : (MODE == WB_SUB ? vc[h] - sv : (MODE == WB_STORE_NEG ? -sv : sv));
+        if (MODE != WB_STORE) *reinterpret_cast<f32x4 *>(sp) = o;  // each thread owns its chunks: the staging area now holds the finals
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o), rC, voff + (unsigned)(half * 8 + h) * rstep, 0, 0);
+      }
+      __syncthreads();
+      if (live && planes_live) {                                   // 64 rows = 8 k8 groups x 32 column quads: one item per thread
+        const int k8 = tid >> 5, c4 = (tid & 31) * 4;
+        float x[8][4];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(smem + (k8 * 8 + r) * LDW + c4);
+          x[r][0] = v[0]; x[r][1] = v[1]; x[r][2] = v[2]; x[r][3] = v[3];
+        }
+        b3_split_store(x, Pp + ((int64_t)(half * 8 + k8) * 3 * pld + c4) * 8, pld);
+      }
+    }
+  }
 }
 
 }  // namespace plmc

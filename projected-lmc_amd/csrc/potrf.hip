@@ -147,11 +147,14 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
 // bx).  The operands are the panel rows of the current group, which k_gpanel_copy / k_wtri_planes also write as k8-ordered
 // bf16 planes into a rolling two-group buffer `Pl` (per buffer b3_elems(128 GMAX, lda) elements, same column coordinates as
 // the factor buffer); tile decoding, skip and depth rules and the write-back are those of k_update, per half.
+// Block rows ib < raw_end are the NEXT group's rows and this is their last update: their final values also go, as planes,
+// into `Praw` (row 128 (ib - ib0) .., same columns) -- the right-hand side of the next group panel (k_gpanel_bf3).
 // grid (nU + Taug + nW, (nrows + 1) / 2, q).
 template <int ROLE>
 __global__ __launch_bounds__(B3_NT, 2) void k_update_bf3(float *A, int64_t lda, int64_t strideA, int ib0, int nrows, int r_lo, int r_hi,
                                                          ColMap<float> cm, int skip_ib, int skip_jb, const unsigned short *__restrict__ Pl,
-                                                         int64_t pl_lat_stride, int64_t wcol0) {
+                                                         int64_t pl_lat_stride, int64_t wcol0, unsigned short *__restrict__ Praw,
+                                                         int64_t praw_lat_stride, int raw_end) {
   if (ROLE == 3) __builtin_amdgcn_s_setprio(2);
   __shared__ __align__(16) unsigned char lds[B3_LDS_BYTES];
   const int bx = blockIdx.x, ibm = ib0 + 2 * (int)blockIdx.y, lat = blockIdx.z;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(B3_NT, 2) void k_update_bf3(float *A, int64_t lda, 
   acc0.zero();
   acc1.zero();
   const unsigned short *Pr = Pl + (int64_t)lat * pl_lat_stride + b3_index(kr0 - r_lo * NB, 0, 0, lda);
-  b3_mainloop(acc0, acc1, Pr + (int64_t)ibm * NB * 8, Pr + colp * 8, lda, depth, lds);
+  b3_mainloop(acc0, acc1, Pr + (int64_t)ibm * NB * 8, lda, Pr + colp * 8, lda, depth, lds);
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -190,8 +193,16 @@ __global__ __launch_bounds__(B3_NT, 2) void k_update_bf3(float *A, int64_t lda, 
   float *C = Cb + (int64_t)(ibm + half) * NB * ldc + col0;
   float *stg = reinterpret_cast<float *>(lds + half * B3_WB_BYTES);
   const bool live = half ? v1 : v0;
-  if (first) tile_writeback<float, WB_STORE_NEG>(acc0, C, ldc, stg, (int)threadIdx.x & 255, live);   // first touch of a W tile
-  else tile_writeback<float, WB_SUB>(acc0, C, ldc, stg, (int)threadIdx.x & 255, live);
+  const int tid = (int)threadIdx.x & 255;
+  if (Praw && ibm < raw_end) {              // uniform per workgroup; a half at or beyond raw_end writes no planes
+    unsigned short *Pp = Praw + (int64_t)lat * praw_lat_stride + b3_index((int64_t)(ibm + half - ib0) * NB, 0, colp, lda);
+    const bool pl = ibm + half < raw_end;
+    if (first) b3_writeback<WB_STORE_NEG, true>(acc0, C, ldc, stg, tid, live, Pp, lda, pl);
+    else b3_writeback<WB_SUB, true>(acc0, C, ldc, stg, tid, live, Pp, lda, pl);
+    return;
+  }
+  if (first) tile_writeback<float, WB_STORE_NEG>(acc0, C, ldc, stg, tid, live);   // first touch of a W tile
+  else tile_writeback<float, WB_SUB>(acc0, C, ldc, stg, tid, live);
 }
 
 // Group panel: U^-T applied to the whole block row of the group as products with Vgg = Ugg^-1 (upper, K-major, leading
@@ -317,6 +328,88 @@ __global__ __launch_bounds__(NTHREADS) void k_wtri_planes(const float *__restric
   b3_split_block<false>(WA + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + (int64_t)(g0 + k) * NB, lda,
                         Pl + (int64_t)lat * pl_lat_stride + b3_index((int64_t)i * NB, 0, wcol0 + (int64_t)(g0 + k) * NB, lda), lda, nullptr, 0,
                         threadIdx.x);
+}
+
+// PLMC_BF16X3 (fp32): Vgg = Ugg^-1 (upper, K-major, the group scratch k_vtrans wrote) as k8-ordered planes with 128 GMAX
+// columns, the A operand of k_gpanel_bf3.  Blocks below the diagonal (k > i) are written as zeros: a macro row of the
+// panel product runs both of its block rows over the depth of the second.  grid (GMAX * GMAX, q).
+__global__ __launch_bounds__(NTHREADS) void k_vg_planes(const float *__restrict__ Vg, int64_t strideG, int G, unsigned short *__restrict__ VgP,
+                                                        int64_t vgp_lat_stride) {
+  const int lat = blockIdx.y, k = (int)blockIdx.x / GMAX, i = (int)blockIdx.x % GMAX;
+  unsigned short *P = VgP + (int64_t)lat * vgp_lat_stride + b3_index((int64_t)k * NB, 0, (int64_t)i * NB, GMAX * NB);
+  if (k <= i && i < G) {
+    b3_split_block<false>(Vg + (int64_t)lat * strideG + (int64_t)k * NB * LDG + (int64_t)i * NB, LDG, P, GMAX * NB, nullptr, 0, threadIdx.x);
+  } else {
+    const b3_s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int w = threadIdx.x; w < 16 * 3 * 128; w += NTHREADS) {          // (k8, plane, column) -> 16 zero bytes
+      const int k8 = w / 384, r = w % 384;
+      *reinterpret_cast<b3_s16x8 *>(P + ((int64_t)k8 * 3 * GMAX * NB + (int64_t)(r / 128) * GMAX * NB + (r % 128)) * 8) = z;
+    }
+  }
+}
+
+// PLMC_BF16X3 (fp32): rows of the factor buffer as planes of `Praw` -- the raw (not yet solved) rows of the FIRST group, which
+// no update kernel has written (every later group's raw rows come out of k_update_bf3).  grid (tiles of the column map, G, q).
+__global__ __launch_bounds__(NTHREADS) void k_raw_planes(const float *__restrict__ A, int64_t lda, int64_t strideA, int g0, ColMap<float> cm,
+                                                         unsigned short *__restrict__ Praw, int64_t praw_lat_stride, int64_t wcol0) {
+  const int lat = blockIdx.z, t = blockIdx.x, i = blockIdx.y;
+  const float *S;
+  int64_t lds_ = lda, colp;
+  if (t < cm.nU) { colp = (int64_t)(cm.u0 + t) * NB; S = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + colp; }
+  else if (t < cm.nU + cm.Taug) { colp = cm.n_pad + (int64_t)(t - cm.nU) * NB; S = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + colp; }
+  else {
+    lds_ = cm.ldw;
+    colp = wcol0 + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
+    S = cm.W + (int64_t)lat * cm.strideW + (int64_t)(g0 + i) * NB * lds_ + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
+  }
+  b3_split_block<false>(S, lds_, Praw + (int64_t)lat * praw_lat_stride + b3_index((int64_t)i * NB, 0, colp, lda), lda, nullptr, 0, threadIdx.x);
+}
+
+// PLMC_BF16X3 (fp32): the group panel on the bf16 matrix cores.  P[i] = sum_{k <= i} Vgg[k][i]^T A[k] for the block rows
+// i of the group and one 128-column strip t of the column map, from the planes of Vgg (VgP, k_vg_planes) and of the raw
+// rows (Praw: k_update_bf3 of the previous group / k_raw_planes).  The operands are read from plane buffers only, so the
+// result goes IN PLACE into the factor buffer -- no panel buffer, no copy kernel -- and, while the tile is in LDS, as planes
+// into the rolling buffer `Pl` for the trailing updates.  A workgroup takes the macro rows (2 a, 2 a + 1) at the depth of
+// the second (the block Vgg[2 a + 1][2 a] is zero in VgP), heavy and light macro rows paired: y and nm - 1 - y.
+// Accuracy: the product with the inverse triangle cancels; tools/split_numerics_probe.hip holds that case (0.37 x the error
+// of the fp32 MFMA chain).  grid (tiles, (nm + 1) / 2, q), nm = (G + 1) / 2.
+__global__ __launch_bounds__(B3_NT, 2) void k_gpanel_bf3(float *A, int64_t lda, int64_t strideA, int g0, int G, ColMap<float> cm,
+                                                         const unsigned short *__restrict__ VgP, int64_t vgp_lat_stride,
+                                                         const unsigned short *__restrict__ Praw, int64_t praw_lat_stride,
+                                                         unsigned short *__restrict__ Pl, int64_t pl_lat_stride, int64_t wcol0) {
+  __shared__ __align__(16) unsigned char lds[B3_LDS_BYTES];
+  const int lat = blockIdx.z, t = blockIdx.x, y = blockIdx.y;
+  float *D;
+  int64_t ldd = lda, colp;
+  if (t < cm.nU) { colp = (int64_t)(cm.u0 + t) * NB; D = A + (int64_t)lat * strideA + (int64_t)g0 * NB * lda + colp; }
+  else if (t < cm.nU + cm.Taug) { colp = cm.n_pad + (int64_t)(t - cm.nU) * NB; D = A + (int64_t)lat * strideA + (int64_t)g0 * NB * lda + colp; }
+  else {
+    ldd = cm.ldw;
+    colp = wcol0 + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
+    D = cm.W + (int64_t)lat * cm.strideW + (int64_t)g0 * NB * ldd + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
+  }
+  const int nm = (G + 1) / 2;
+  const unsigned short *Vp = VgP + (int64_t)lat * vgp_lat_stride, *Rp = Praw + (int64_t)lat * praw_lat_stride + colp * 8;
+  unsigned short *Pp = Pl + (int64_t)lat * pl_lat_stride + colp * 8;
+  const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), tid = (int)threadIdx.x & 255;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int a = pass == 0 ? nm - 1 - y : (y < nm - 1 - y ? y : -1);
+    if (a < 0) break;
+    const int i0 = 2 * a, rows = G - i0 < 2 ? G - i0 : 2;
+    Acc<float> acc0, acc1;
+    acc0.zero();
+    acc1.zero();
+    b3_mainloop(acc0, acc1, Vp + (int64_t)i0 * NB * 8, (int64_t)GMAX * NB, Rp, lda, (i0 + rows) * NB, lds);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc0.v[u][v] += acc1.v[u][v];
+    const int i = i0 + half;
+    b3_writeback<WB_STORE, true>(acc0, D + (int64_t)i * NB * ldd, ldd, reinterpret_cast<float *>(lds + half * B3_WB_BYTES), tid, half < rows,
+                                 Pp + (int64_t)i * 16 * 3 * lda * 8, lda);
+    __syncthreads();                     // staging areas free before the next product's DMA lands
+  }
 }
 
 // K^-1 accumulation inside the sweep (with_inverse = 2).  Khat^-1 = W^T W = sum over groups of W[R]^T W[R] (R = the block
@@ -482,6 +575,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const bool bf3 = sizeof(T) == 4 && knobs().bf16x3;
   const int64_t pl_buf = b3_elems((int64_t)GMAX * NB, lda);             // 16-bit elements of one group's planes (k8 order)
   unsigned short *const Pl0 = bf3 ? reinterpret_cast<unsigned short *>(Pbulk + (int64_t)GMAX * NB * lda) : nullptr;
+  unsigned short *const Praw = bf3 ? Pl0 + 2 * pl_buf : nullptr;         // raw rows of the group whose panel comes next (one group)
+  unsigned short *const VgP = bf3 ? Praw + pl_buf : nullptr;             // planes of Vgg: b3_elems(128 GMAX, 128 GMAX)
   const int64_t pl_lat = strideV * (int64_t)(sizeof(T) / 2);            // latent stride in 16-bit elements
   const int grp_rows = (knobs().grp > 0 && knobs().grp < GMAX) ? knobs().grp : GMAX;   // block rows per group (as below)
   auto planes = [&](int g0) -> unsigned short * {                       // buffer of the group that starts at block row g0
@@ -528,8 +623,10 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // cls: profiler class of the launch -- PK_TRAIL (the big trailing update), PK_TRAIL_HEAD (look-ahead updates of the next
   // group's rows: `crit` = the triangle on the chain stream, else the other columns on the second helper stream),
   // PK_TRAIL_ROW (rank-128 update inside a group's triangle)
+  // raw_end (PLMC_BF16X3): block rows below it are the next group's -- this launch is their last update and also writes
+  // their planes (Praw) for the next group panel
   auto update = [&](int ib0, int nrows, int r_lo, int r_hi, const ColMap<T> &cm, hipStream_t s, int cls, int skip_ib = 0,
-                    int skip_jb = 0, bool crit = false) {
+                    int skip_jb = 0, bool crit = false, int raw_end = 0) {
     const int Cn = cm.nU + cm.Taug + cm.nW;
     if (nrows <= 0 || Cn == 0) return;
     const double depth = (r_hi - r_lo + 1) * nb, nr = (double)nrows;
@@ -565,9 +662,11 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
         const unsigned short *pl = planes(r_lo);
         const dim3 gridb(Cn, (nrows + 1) / 2, q);
         if (cls == PK_TRAIL)
-          hipLaunchKernelGGL((k_update_bf3<0>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cm, skip_ib, skip_jb, pl, pl_lat, wcol0);
+          hipLaunchKernelGGL((k_update_bf3<0>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cm, skip_ib, skip_jb, pl, pl_lat, wcol0,
+                             Praw, pl_lat, raw_end);
         else
-          hipLaunchKernelGGL((k_update_bf3<3>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cm, skip_ib, skip_jb, pl, pl_lat, wcol0);
+          hipLaunchKernelGGL((k_update_bf3<3>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cm, skip_ib, skip_jb, pl, pl_lat, wcol0,
+                             Praw, pl_lat, raw_end);
         return;
       }
     }
@@ -584,6 +683,15 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     const int nt = cm.nU + cm.Taug + cm.nW;
     if (nt == 0) return;
     const double prods = G * (G + 1) / 2.0;               // 128-deep tile products per column strip
+    if constexpr (sizeof(T) == 4) {
+      if (bf3 && !head) {                                  // bf16 engine, in place, planes from the epilogue (k_gpanel_bf3)
+        ProfScope ps(PK_GPANEL, s, q * (double)nt * prods * 2.0 * nb3, q * (double)nt * (prods + G) * nb * nb * esz);
+        const int nm = (G + 1) / 2;
+        hipLaunchKernelGGL(k_gpanel_bf3, dim3(nt, (nm + 1) / 2, q), dim3(B3_NT), 0, s, A, lda, strideA, g0, G, cm, (const unsigned short *)VgP, pl_lat,
+                           (const unsigned short *)Praw, pl_lat, planes(g0), pl_lat, wcol0);
+        return;
+      }
+    }
     T *Pb = head ? Ph : Pbulk;
     const int64_t ldp = head ? (int64_t)LDG : lda;
     {
@@ -660,6 +768,23 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       hipLaunchKernelGGL(k_wtri_planes, dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const float *)WA, lda, strideA, g0, planes(g0), pl_lat, wcol0);
     }
   };
+  // PLMC_BF16X3: planes of Vgg for the group panel (behind k_vtrans; same stream as the panel that reads them)
+  auto vg_planes = [&](int gi, hipStream_t s) {
+    if constexpr (sizeof(T) == 4) {
+      if (!bf3) return;
+      hipLaunchKernelGGL(k_vg_planes, dim3(GMAX * GMAX, q), dim3(NTHREADS), 0, s, (const float *)Vg2[gi & 1], strideV, G0(gi + 1) - G0(gi), VgP, pl_lat);
+    }
+  };
+  // PLMC_BF16X3: planes of the first group's raw rows (columns of the bulk panel: everything right of the second group + aug)
+  auto raw_planes0 = [&](hipStream_t s, int u0) {
+    if constexpr (sizeof(T) == 4) {
+      if (!bf3) return;
+      const int g1 = G0(1);
+      const ColMap<float> cm = cm_buf(u0, m - u0, Taug, 0, 0);
+      const int nt = cm.nU + cm.Taug + cm.nW;
+      if (nt > 0) hipLaunchKernelGGL(k_raw_planes, dim3(nt, g1, q), dim3(NTHREADS), 0, s, (const float *)A, lda, strideA, 0, cm, Praw, pl_lat, wcol0);
+    }
+  };
 
   auto kacc = [&](int gi, hipStream_t s) {
     if (!kacc_on) return;
@@ -671,7 +796,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     hipLaunchKernelGGL((k_kacc<T>), dim3(nt, q), dim3(NTHREADS), bulk_lds, s, A, lda, strideA, (const T *)WA, lda, strideA, Kd, strideV, g0, g1);
   };
 
-  hipStream_t C = serial ? nullptr : side_stream(), H = serial ? nullptr : side_stream(1);
+  // PLMC_BULK_STREAMS=1: the group panel of the other columns and the head rows ride on the caller's stream, in front of the tail
+  hipStream_t C = serial ? nullptr : side_stream(), H = serial ? nullptr : (kn.bulk_streams == 1 ? st : side_stream(1));
   // the K^-1 accumulation rides on the caller's stream behind the tail (e_tail is recorded before it, so nothing on the
   // critical path waits for it).  A stream of its own shared a hardware queue with one of the others (HIP maps streams
   // onto four hardware queues; with the gradient stream of the Python layer this library already uses four) and
@@ -681,15 +807,25 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const bool la = C && H && e_entry && e_v && e_gh && e_p && e_hd && e_tail && e_doneC && e_doneH && e_doneK && ng > 2;
   if (!la) {
     // one stream: chain -> transpose -> group panel over every column -> trailing update of every row below
+    // PLMC_BF16X3: which engine a tile goes through must not depend on the schedule -- as under the look-ahead, the panel
+    // columns of the next group and its triangle update (U1) take the fp32 MFMAs, everything else the bf16 engine
+    raw_planes0(st, G0(2));
     for (int gi = 0; gi < ng; ++gi) {
       const int g0 = G0(gi), g1 = G0(gi + 1);
       chain(gi, st);
       vtrans(gi, st);
       wtri_planes(gi, st);
-      gpanel(g0, g1 - g0, cm_buf(g1, m - g1, Taug, 0, g0), Vg2[gi & 1], st, 0);
-      if (bf3) {             // as under the look-ahead: the next group's triangle on the fp32 MFMAs, the rest on bf16x3
+      vg_planes(gi, st);
+      if (bf3) {
         const int g2 = G0(gi + 2);
-        update(g1, m - g1, g0, g1 - 1, cm_buf(g1, m - g1, Taug, 0, g1), st, PK_TRAIL, g2, g2);
+        gpanel(g0, g1 - g0, cm_buf(g1, g2 - g1, 0, 0, 0), Vg2[gi & 1], st, 1);
+        gpanel(g0, g1 - g0, cm_buf(g2, m - g2, Taug, 0, g0), Vg2[gi & 1], st, 0);
+      } else {
+        gpanel(g0, g1 - g0, cm_buf(g1, m - g1, Taug, 0, g0), Vg2[gi & 1], st, 0);
+      }
+      if (bf3) {
+        const int g2 = G0(gi + 2);
+        update(g1, m - g1, g0, g1 - 1, cm_buf(g1, m - g1, Taug, 0, g1), st, PK_TRAIL, g2, g2, false, g2);
         update(g1, g2 - g1, g0, g1 - 1, cm_buf(g1, g2 - g1, 0, 0, 0), st, PK_TRAIL_HEAD, 0, 0, true);
       } else {
         update(g1, m - g1, g0, g1 - 1, cm_buf(g1, m - g1, Taug, 0, g1), st, PK_TRAIL);
@@ -713,6 +849,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   (void)hipEventRecord(e_entry, st);
   (void)hipStreamWaitEvent(C, e_entry, 0);
   (void)hipStreamWaitEvent(H, e_entry, 0);
+  raw_planes0(H, G0(2));
   for (int gi = 0; gi < ng; ++gi) {
     const int g0 = G0(gi), g1 = G0(gi + 1), g2 = G0(gi + 2), G = g1 - g0;
     const T *Vg = Vg2[gi & 1];
@@ -727,11 +864,12 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
 
     (void)hipStreamWaitEvent(H, e_v, 0);
     wtri_planes(gi, H);
+    vg_planes(gi, H);
     gpanel(g0, G, cm_buf(g2, m - g2, Taug, 0, g0), Vg, H, 0);                   // rest of the panel columns
     (void)hipEventRecord(e_p, H);
     (void)hipStreamWaitEvent(H, e_gh, 0);
     if (gi > 0) (void)hipStreamWaitEvent(H, e_tail, 0);
-    update(g1, g2 - g1, g0, g1 - 1, cm_buf(g2, m - g2, Taug, 0, g1), H, PK_TRAIL_HEAD);   // head: rows R1, columns right of R1
+    update(g1, g2 - g1, g0, g1 - 1, cm_buf(g2, m - g2, Taug, 0, g1), H, PK_TRAIL_HEAD, 0, 0, false, g2);   // head: rows R1, columns right of R1
     (void)hipEventRecord(e_hd, H);
 
     (void)hipStreamWaitEvent(st, e_p, 0);
@@ -784,12 +922,14 @@ int w_diag_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, T *kinv
 
 extern "C" {
 // Vd blocks per latent: m diagonal inverses + the fixed group scratch + the bulk panel buffer (GMAX block rows of lda) + m
-// diagonal K^-1 tiles; for 4-byte elements also the rolling bf16 plane buffer of the bf16 engine (2 groups x 3 planes x
-// 128 GMAX rows x lda 16-bit elements = 3 GMAX lda / 128 fp32 blocks) -- whether or not PLMC_BF16X3 is on, so that a
-// workspace never depends on a knob.
+// diagonal K^-1 tiles; for 4-byte elements also the bf16 plane buffers of the bf16 engine -- whether or not PLMC_BF16X3 is
+// on, so that a workspace never depends on a knob.
 int64_t plmc_vd_blocks_for(int64_t n_pad, int64_t lda, int elem_bytes) {
   const int64_t ldb = (lda + plmc::NB - 1) / plmc::NB;
-  return 2 * (n_pad / plmc::NB) + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ldb + (elem_bytes == 4 ? 3 * plmc::GMAX * ldb : 0);
+  // planes (4-byte elements): rolling buffer of the solved panel rows (2 groups) + raw rows of the next group (1 group), each
+  // 128 GMAX rows x 3 planes x lda x 2 bytes = 12 ldb blocks at GMAX = 8, + Vgg (3 x (128 GMAX)^2 x 2 bytes = 96 blocks)
+  const int64_t planes = elem_bytes == 4 ? 3 * (3 * plmc::GMAX * ldb / 2) + 6 * plmc::GMAX * plmc::GMAX / 4 : 0;
+  return 2 * (n_pad / plmc::NB) + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ldb + planes;
 }
 int64_t plmc_vd_blocks(int64_t n_pad, int64_t lda) { return plmc_vd_blocks_for(n_pad, lda, 4); }
 int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet,

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(B3_NT, 2) void k_kinv_grad_bf3(int kind, int64_t n_
   acc0.zero();
   acc1.zero();
   const unsigned short *Pl = Wp + (int64_t)lat * b3_elems(n_pad, n_pad) + b3_index((int64_t)jb * NB, 0, 0, n_pad);
-  b3_mainloop(acc0, acc1, Pl + (int64_t)ibm * NB * 8, Pl + (int64_t)jb * NB * 8, n_pad, (int)(n_pad - (int64_t)jb * NB), lds);
+  b3_mainloop(acc0, acc1, Pl + (int64_t)ibm * NB * 8, n_pad, Pl + (int64_t)jb * NB * 8, n_pad, (int)(n_pad - (int64_t)jb * NB), lds);
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(B3_NT, 2) void k_bf3v2_tiles(const unsigned short *
   Acc<float> acc0, acc1;
   acc0.zero();
   acc1.zero();
-  b3_mainloop(acc0, acc1, P + (int64_t)mb * 256 * 8, P + (int64_t)jb * NB * 8, ld, K, lds);
+  b3_mainloop(acc0, acc1, P + (int64_t)mb * 256 * 8, ld, P + (int64_t)jb * NB * 8, ld, K, lds);
   const int tid = threadIdx.x & 255, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
 #pragma unroll
   for (int a = 0; a < 4; ++a)

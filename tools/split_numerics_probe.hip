@@ -140,13 +140,55 @@ template <int MODE> static void launch(const float *A, const float *B, int K, fl
 
 int main() {
   const int Ks[2] = {1024, 8192};
-  for (int dist = 0; dist < 3; ++dist)
+  for (int dist = 0; dist < 4; ++dist)
     for (int ki = 0; ki < 2; ++ki) {
       const int K = Ks[ki];
+      if (dist == 3 && ki == 1) continue;
       std::mt19937_64 rng(1234 + dist * 7 + ki);
       std::normal_distribution<double> nd(0.0, 1.0);
       std::vector<float> A((size_t)K * 128), B((size_t)K * 128);
-      for (size_t i = 0; i < A.size(); ++i) {
+      if (dist == 3) {
+        // The group panel of the sweep, with its cancellation: A = V = U^-1 (upper, K-major) of a smooth kernel matrix
+        // (Matern-5/2, 1024 points in 8 dimensions, lengthscale 1, noise 1e-4), B = U^T P for a random P, so that the
+        // exact product V^T B = P is O(1) while the summands are not.  Reference: fp64 product of the fp32-rounded inputs.
+        const int n = K;
+        std::vector<double> X((size_t)n * 8), Km((size_t)n * n), U((size_t)n * n, 0.0), V((size_t)n * n, 0.0);
+        std::uniform_real_distribution<double> ud(-1.0, 1.0);
+        for (auto &v : X) v = ud(rng);
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j < n; ++j) {
+            double r2 = 0; for (int k = 0; k < 8; ++k) { double dd = X[(size_t)i * 8 + k] - X[(size_t)j * 8 + k]; r2 += dd * dd; }
+            const double r = sqrt(5.0 * r2);
+            Km[(size_t)i * n + j] = (1.0 + r + r * r / 3.0) * exp(-r) + (i == j ? 1e-4 : 0.0);
+          }
+        for (int j = 0; j < n; ++j) {                       // K = U^T U, U upper
+          for (int i = 0; i <= j; ++i) {
+            double sum = Km[(size_t)i * n + j];
+            for (int k = 0; k < i; ++k) sum -= U[(size_t)k * n + i] * U[(size_t)k * n + j];
+            U[(size_t)i * n + j] = i == j ? sqrt(sum) : sum / U[(size_t)i * n + i];
+          }
+        }
+        for (int c = 0; c < 128; ++c) {                      // V[:, c'] for the LAST 128 columns only (the heaviest rows of the panel)
+          const int col = n - 128 + c;
+          std::vector<double> x(n, 0.0);
+          for (int i = col; i >= 0; --i) {                   // solve U x = e_col
+            double sum = (i == col) ? 1.0 : 0.0;
+            for (int k = i + 1; k <= col; ++k) sum -= U[(size_t)i * n + k] * x[k];
+            x[i] = sum / U[(size_t)i * n + i];
+          }
+          for (int k = 0; k < n; ++k) A[(size_t)k * 128 + c] = (float)x[k];
+        }
+        std::vector<double> Pt((size_t)n * 128);
+        for (auto &v : Pt) v = nd(rng);
+        for (int k = 0; k < n; ++k)                          // B = U^T P: B[k][j] = sum_{l <= k} U[l][k] P[l][j]
+          for (int j = 0; j < 128; ++j) {
+            double sum = 0; for (int l = 0; l <= k; ++l) sum += U[(size_t)l * n + k] * Pt[(size_t)l * 128 + j];
+            B[(size_t)k * 128 + j] = (float)sum;
+          }
+        double amax = 0; for (auto v : A) amax = fmax(amax, fabs((double)v));
+        printf("   (largest |V| entry %.3e)\n", amax);
+      }
+      for (size_t i = 0; dist < 3 && i < A.size(); ++i) {
         double a = nd(rng), b = nd(rng);
         if (dist == 1) { a *= exp(3.0 * nd(rng)); b *= exp(3.0 * nd(rng)); }      // wide dynamic range
         if (dist == 2) { a = fabs(a) + 0.5; b = fabs(b) + 0.5; }                   // one sign: sums grow like K, no cancellation
@@ -165,7 +207,7 @@ int main() {
       CK(hipMalloc(&dA, A.size() * 4)); CK(hipMalloc(&dB, B.size() * 4)); CK(hipMalloc(&dC, 128 * 128 * 4));
       CK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
       CK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));
-      printf("== data %s, K = %d\n", dist == 0 ? "N(0,1)" : (dist == 1 ? "N(0,1) x exp(3 N(0,1)) (wide range)" : "|N(0,1)| + 0.5 (one sign)"), K);
+      printf("== data %s, K = %d\n", dist == 0 ? "N(0,1)" : (dist == 1 ? "N(0,1) x exp(3 N(0,1)) (wide range)" : (dist == 2 ? "|N(0,1)| + 0.5 (one sign)" : "group panel V^T (U^T P), Matern-5/2 + 1e-4 I (cancellation)")), K);
       std::vector<float> C((size_t)128 * 128);
       double e_f32_max = 0, e_f32_rms = 0;
       for (int mode = 0; mode < M_COUNT; ++mode) {
