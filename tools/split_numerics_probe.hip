@@ -29,10 +29,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-enum Mode { M_F32 = 0, M_B6_1, M_B6_2, M_B6_3, M_B8_1, M_B8_2, M_B8_3, M_B9_2, M_B9_3, M_H6_3, M_H6_2, M_HH, M_B3_1, M_COUNT };
+enum Mode { M_F32 = 0, M_B6_1, M_B6_2, M_B6_3, M_B8_1, M_B8_2, M_B8_3, M_B9_2, M_B9_3, M_H6_3, M_H6_2, M_HH, M_B3_1, M_H3_2, M_H4_2, M_COUNT };
 static const char *mode_name[M_COUNT] = {"f32 mfma chain", "bf16x3 6 prod 1 lvl", "bf16x3 6 prod 2 lvl", "bf16x3 6 prod 3 lvl", "bf16x3 8 prod 1 lvl",
                                          "bf16x3 8 prod 2 lvl", "bf16x3 8 prod 3 lvl", "bf16x3 9 prod 2 lvl", "bf16x3 9 prod 3 lvl",
-                                         "fp16x3 6 prod 3 lvl", "fp16x3 6 prod 2 lvl", "bf16 hi.hi only   ", "bf16x2 3 prod 1 lvl"};
+                                         "fp16x3 6 prod 3 lvl", "fp16x3 6 prod 2 lvl", "bf16 hi.hi only   ", "bf16x2 3 prod 1 lvl",
+                                         "fp16x2 3 prod 2 lvl", "fp16x2 4 prod 2 lvl"};
 
 __device__ __forceinline__ void split_bf(const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
 #pragma unroll
@@ -75,12 +76,16 @@ __global__ __launch_bounds__(64) void k_probe(const float *__restrict__ A, const
         xa[j] = A[(int64_t)(k + 8 * fg + j) * 128 + ti * 16 + fr];
         xb[j] = B[(int64_t)(k + 8 * fg + j) * 128 + tj * 16 + fr];
       }
-      if constexpr (MODE == M_H6_3 || MODE == M_H6_2) {
+      if constexpr (MODE == M_H6_3 || MODE == M_H6_2 || MODE == M_H3_2 || MODE == M_H4_2) {
         f16x8 ah, am, al, bh, bm, bl;
         split_h(xa, ah, am, al);
         split_h(xb, bh, bm, bl);
 #define MMH(x, y, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0)
-        if constexpr (MODE == M_H6_3) {
+        if constexpr (MODE == M_H3_2 || MODE == M_H4_2) {     // two fp16 planes (22 bits): h0.h0 | (h1.h0 + h0.h1 [+ h1.h1 2^-11])
+          if constexpr (MODE == M_H4_2) { f32x4 t = {0, 0, 0, 0}; MMH(am, bm, t); acc1 += t * (1.0f / 2048.0f); }
+          MMH(am, bh, acc1); MMH(ah, bm, acc1);
+          MMH(ah, bh, acc0);
+        } else if constexpr (MODE == M_H6_3) {
           MMH(al, bh, acc2); MMH(ah, bl, acc2); MMH(am, bm, acc2);
           MMH(am, bh, acc1); MMH(ah, bm, acc1);
           MMH(ah, bh, acc0);
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(64) void k_probe(const float *__restrict__ A, const
   }
   f32x4 r;
   if constexpr (MODE == M_H6_3) r = acc0 + (acc1 + acc2 * (1.0f / 2048.0f)) * (1.0f / 2048.0f);
-  else if constexpr (MODE == M_H6_2) r = acc0 + acc1 * (1.0f / 2048.0f);
+  else if constexpr (MODE == M_H6_2 || MODE == M_H3_2 || MODE == M_H4_2) r = acc0 + acc1 * (1.0f / 2048.0f);
   else r = acc0 + (acc1 + acc2);
   // C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg
 #pragma unroll
@@ -213,7 +218,7 @@ int main() {
       for (int mode = 0; mode < M_COUNT; ++mode) {
         switch (mode) {
 #define CASE(M) case M: launch<M>(dA, dB, K, dC); break;
-          CASE(M_F32) CASE(M_B6_1) CASE(M_B6_2) CASE(M_B6_3) CASE(M_B8_1) CASE(M_B8_2) CASE(M_B8_3) CASE(M_B9_2) CASE(M_B9_3) CASE(M_H6_3) CASE(M_H6_2) CASE(M_HH) CASE(M_B3_1)
+          CASE(M_F32) CASE(M_B6_1) CASE(M_B6_2) CASE(M_B6_3) CASE(M_B8_1) CASE(M_B8_2) CASE(M_B8_3) CASE(M_B9_2) CASE(M_B9_3) CASE(M_H6_3) CASE(M_H6_2) CASE(M_HH) CASE(M_B3_1) CASE(M_H3_2) CASE(M_H4_2)
 #undef CASE
         }
         CK(hipDeviceSynchronize());
