@@ -30,14 +30,16 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6, "bf16": 2500.0}     # MI355X_MICROARCH.md chip table (dense matrix peaks)
-SPLIT_PRODUCTS = 6          # bf16 plane products per fp32 product in the split engine (csrc/bf3_engine.hpp)
+SPLIT_PRODUCTS = {2: 3, 3: 6}          # 16-bit plane products per fp32 product in the split engines (csrc/bf3_engine.hpp)
 ARITHMETIC = {
-    True: "fp32 storage, results and accumulation; the bulk products (tail / head updates of the sweep, K^-1 = W^T W) on "
-          "v_mfma_f32_16x16x32_bf16 from operands split exactly into three bf16 planes (x = hi + mid + lo), six plane products "
-          "into two fp32 accumulator levels (error vs fp64 0.3-0.4 x the fp32 MFMA chain's, profiles/r03_split_numerics.txt); "
-          "chain, group panel and look-ahead updates on v_mfma_f32_16x16x4_f32",
-    False: "fp32 storage and arithmetic: every product on v_mfma_f32_16x16x4_f32 (PLMC_BF16X3=0)"}
-HBM_PEAK_GBS = 8000.0
+    2: "fp32 storage, results and accumulation; the bulk products (tail / head updates and group panels of the sweep, K^-1 = W^T W) "
+       "on v_mfma_f32_16x16x32_f16 from operands split into two fp16 planes (s x = h0 + 2^-11 h1, 22 bits; s = a power of two from "
+       "bounds by the largest diagonal entry and the noise), three plane products into two fp32 accumulator levels (error vs fp64 "
+       "0.3-0.45 x the fp32 MFMA chain's, profiles/r03_split_numerics.txt); chain, next-group panel columns, look-ahead updates and "
+       "augmented columns on v_mfma_f32_16x16x4_f32",
+    3: "as the default, but the bulk products on v_mfma_f32_16x16x32_bf16 from three bf16 planes (x = hi + mid + lo exactly), six plane "
+       "products into two fp32 accumulator levels (PLMC_SPLIT=3)",
+    0: "fp32 storage and arithmetic: every product on v_mfma_f32_16x16x4_f32 (PLMC_SPLIT=0)"}
 
 
 def make_data(n, d, p, q, seed=0, dtype=torch.float32):
@@ -334,29 +336,34 @@ def main():
             fence()
             iso = _hip.prof_collect()
         _hip.prof_enable(False)
-    # The same steps with PLMC_BF16X3=0 -- every product on the fp32 matrix instruction -- reported BESIDE the headline with its
-    # own accuracy checks at the same checkpoint states (the split engine is the default only while its
-    # errors are at or below this path's).
-    split_on = os.environ.get("PLMC_BF16X3", "1") != "0"
-    option = None
-    if world == 1 and not args.no_options and split_on:
-        try:
-            with _hip.knob("PLMC_BF16X3", "0"):
-                for i in range(2):
-                    step()
-                fence()
-                t0 = time.perf_counter()
-                for i in range(args.steps):
-                    step()
-                fence()
-                el = time.perf_counter() - t0
-                option = {"ms_per_step": 1e3 * el / args.steps, "iters_per_sec": args.steps / el}
-                if do_checks and st5 is not None:
-                    gpu_checkpoint("after %d optimiser steps [fp32 mfma]" % n_check, st5, sorted({0, q - 1}))
-                    model.train()
-        except Exception as exc:                            # the comparison run must never cost the headline line
-            option = {"error": "%s: %s" % (type(exc).__name__, exc)}
-            checkpoints[:] = [c for c in checkpoints if not c[0].endswith("[fp32 mfma]")]
+    # The same steps with the other arithmetics of the bulk products -- PLMC_SPLIT=0: every product on the fp32 matrix
+    # instruction; PLMC_SPLIT=3: three bf16 planes -- reported BESIDE the headline with their own accuracy checks at the same
+    # checkpoint states (a split engine is the default only while its errors are at or below the fp32 path's).
+    split = int(os.environ.get("PLMC_SPLIT", "2"))
+    split = split if split in (0, 3) else 2
+    options = {}
+    if world == 1 and not args.no_options:
+        for alt in (0, 3):
+            if alt == split:
+                continue
+            tag = " [split %d]" % alt
+            try:
+                with _hip.knob("PLMC_SPLIT", str(alt)):
+                    for i in range(2):
+                        step()
+                    fence()
+                    t0 = time.perf_counter()
+                    for i in range(args.steps):
+                        step()
+                    fence()
+                    el = time.perf_counter() - t0
+                    options[alt] = {"ms_per_step": 1e3 * el / args.steps, "iters_per_sec": args.steps / el}
+                    if do_checks and st5 is not None:
+                        gpu_checkpoint("after %d optimiser steps%s" % (n_check, tag), st5, sorted({0, q - 1}))
+                        model.train()
+            except Exception as exc:                            # a comparison run must never cost the headline line
+                options[alt] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                checkpoints[:] = [c for c in checkpoints if not c[0].endswith(tag)]
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -367,7 +374,7 @@ def main():
         res = {
             "metric": "MLL+grad iters/sec, n=8192 16-task LMC", "value": its, "unit": "iters/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "arithmetic": ARITHMETIC[split_on],
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "arithmetic": ARITHMETIC[split],
             "data": "synthetic",
             "config": {"workload": "C3: ProjectedGPModel+ProjectedLMCmll exact training step (%s), n=%d d=%d p=%d q=%d "
                                    "Matern-5/2 fp32; latents sharded q/N per GPU" % (args.variant, n, d, p, q),
@@ -386,14 +393,14 @@ def main():
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
             # the three bracketed classes are exactly the launches the split engine carries: their peak is the dense bf16 peak
             # divided by the six plane products one fp32 product costs (fp32-equivalent TFLOP/s); with PLMC_BF16X3=0 the fp32 peak
-            peak = MFMA_PEAK_TFLOPS["bf16"] / SPLIT_PRODUCTS if split_on else MFMA_PEAK_TFLOPS["f32"]
-            try:                                                  # bare instruction stream on this device, now
-                peak_meas = (_hip.mfma_rate("bf16", dev) / SPLIT_PRODUCTS) if split_on else _hip.mfma_rate(torch.float32, dev)
+            peak = MFMA_PEAK_TFLOPS["bf16"] / SPLIT_PRODUCTS[split] if split else MFMA_PEAK_TFLOPS["f32"]
+            try:                                                  # bare instruction stream on this device, now (f16 runs at the bf16 rate)
+                peak_meas = (_hip.mfma_rate("bf16", dev) / SPLIT_PRODUCTS[split]) if split else _hip.mfma_rate(torch.float32, dev)
             except Exception:
                 peak_meas = None
             res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "peak_note": ("fp32-equivalent: dense bf16 MFMA peak %.0f / %d plane products" % (MFMA_PEAK_TFLOPS["bf16"], SPLIT_PRODUCTS))
-                               if split_on else "dense fp32 MFMA peak",
+                               "peak_note": ("fp32-equivalent: dense 16-bit MFMA peak %.0f / %d plane products" % (MFMA_PEAK_TFLOPS["bf16"], SPLIT_PRODUCTS[split]))
+                               if split else "dense fp32 MFMA peak",
                                "frac": ach / peak, "traffic": None, "peak_measured": peak_meas,
                                "frac_of_measured_peak": (ach / peak_meas) if peak_meas else None,
                                "avg_launch_ms": s["ms"] / s["launches"], "launches": s["launches"],
@@ -407,7 +414,9 @@ def main():
             # HBM bytes per launch from the PMC counters.  They cannot be read from inside the process: they come from
             # rocprofv3 --pmc passes of this same command -- the committed ones if they were measured on THIS build
             # (build key over the library sources), else (--pmc) two child runs now, else null.
-            kname = ({"k_trail": "k_update_bf3<0>", "k_trail_head": "k_update_bf3<3>", "k_kinv_grad": "k_kinv_grad_bf3<8, false>"} if split_on else
+            sname = {2: "plmc::SplitH2", 3: "plmc::SplitB3"}.get(split)
+            kname = ({"k_trail": "k_update_bf3<%s, 0>" % sname, "k_trail_head": "k_update_bf3<%s, 3>" % sname,
+                      "k_kinv_grad": "k_kinv_grad_bf3<%s, 8, false>" % sname} if split else
                      {"k_trail": "k_update<float, 0, 4>", "k_trail_head": "k_update<float, 3, 4>",
                       "k_kinv_grad": "k_kinv_grad<float, 8, false>"}).get(dom, dom + "<float>")
             if world == 1:
@@ -448,13 +457,14 @@ def main():
             res["speedup_vs_cpu"] = its / cb["value"]
             note("fp64 oracle at the %d accuracy checkpoints ..." % len(checkpoints))
             checks = []
-            opt_checks, memo = [], {}
+            opt_checks, memo = {}, {}
             for label, j, e, z, yt, lp_gpu, g_gpu in checkpoints:
-                key = (j, label.replace(" [fp32 mfma]", ""))
+                key = (j, label.split(" [split")[0])
                 if key not in memo:
                     memo[key] = oracle_latent(X, e, z, yt)
                 lp_cpu, g_cpu = memo[key]
-                (opt_checks if label.endswith("[fp32 mfma]") else checks).append(
+                alt = int(label.split("[split ")[1][:-1]) if "[split " in label else None
+                (opt_checks.setdefault(alt, []) if alt is not None else checks).append(
                     {"where": "latent %d, %s" % (j, label), "logp_hip_f32": lp_gpu, "logp_oracle_f64": lp_cpu,
                      "loglik_rel_err": abs(lp_gpu - lp_cpu) / abs(lp_cpu),
                      "grad_rel_err": float((g_gpu - g_cpu).norm() / g_cpu.norm()),
@@ -462,17 +472,18 @@ def main():
             res["loglik_rel_err"] = max(c["loglik_rel_err"] for c in checks)
             res["grad_rel_err"] = max(c["grad_rel_err"] for c in checks)
             res["accuracy_checks"] = checks
-            if option is not None and opt_checks:
-                option["loglik_rel_err"] = max(c["loglik_rel_err"] for c in opt_checks)
-                option["grad_rel_err"] = max(c["grad_rel_err"] for c in opt_checks)
-                option["accuracy_checks"] = opt_checks
+            for alt, oc in opt_checks.items():
+                if alt in options and "error" not in options[alt]:
+                    options[alt]["loglik_rel_err"] = max(c["loglik_rel_err"] for c in oc)
+                    options[alt]["grad_rel_err"] = max(c["grad_rel_err"] for c in oc)
+                    options[alt]["accuracy_checks"] = oc
             res["accuracy_note"] = ("log N(y~; 0, K + s2 I) of a latent GP and its gradient w.r.t. every lengthscale, the noise and "
                                     "all n projected targets (d + 1 + n numbers), fp32 HIP vs fp64 CPU oracle at n = %d; max over the "
                                     "checkpoints in loglik_rel_err / grad_rel_err" % n)
         res["first_loss"] = first_loss
-        if option is not None:
-            option["what"] = ("NOT the headline: the same %d steps with PLMC_BF16X3=0 -- " % args.steps) + ARITHMETIC[False]
-            res["fp32_mfma_option"] = option
+        for alt, opt in options.items():
+            opt["what"] = ("NOT the headline: the same %d steps with PLMC_SPLIT=%d -- " % (args.steps, alt)) + ARITHMETIC[alt]
+            res["fp32_mfma_option" if alt == 0 else "bf16x3_option"] = opt
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -116,6 +116,22 @@ int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strid
                    double *logdet, int *info, int with_inverse, int q, void *stream);
 int plmc_potrf_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, double *Vd,
                    double *logdet, int *info, int with_inverse, int q, void *stream);
+/* The same with `eig_lo`: q lower bounds of the smallest eigenvalue of the input matrices (device pointer; for a GP
+ * covariance K + s2 I the noise variances s2, since K is positive semi-definite).  Arithmetic of the BULK fp32 products
+ * (tail / head updates, group panel; environment PLMC_SPLIT, default 2):
+ *   2  two fp16 planes per operand, s x = h0 + 2^-11 h1 (22 bits), three plane products on v_mfma_f32_16x16x32_f16 into two
+ *      fp32 accumulator levels.  Every operand family is scaled by a power of two that puts a rigorous bound of its
+ *      magnitude -- from the largest diagonal entry D and eig_lo: sqrt(D), D, 1/sqrt(eig_lo), sqrt(D/eig_lo) -- at 2^13, so fp16
+ *      cannot overflow; the augmented columns (no a-priori bound) stay on the fp32 MFMAs.  Needs eig_lo; without it ->
+ *   3  three bf16 planes (x = hi + mid + lo exactly), six plane products, two accumulator levels: any data, no scaling.
+ *   0  v_mfma_f32_16x16x4_f32 everywhere.
+ * Either split has 0.3-0.45 x the error of the fp32 MFMA chain against fp64 (profiles/r03_split_numerics.txt).  The chain
+ * (diagonal blocks, rank-128 updates), the panel columns of the next group and every fp64 product use the MFMA of the
+ * element type.  A wrong (too large) eig_lo can overflow fp16: the result is then inf / nan and `info` reports it. */
+int plmc_potrf_ex_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet,
+                      int *info, int with_inverse, int q, const float *eig_lo, void *stream);
+int plmc_potrf_ex_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, double *Vd, double *logdet,
+                      int *info, int with_inverse, int q, const double *eig_lo, void *stream);
 
 /*
  * Gather augmented column c of every latent into a contiguous vector z (q x n_pad) and return
@@ -192,9 +208,8 @@ int plmc_w_diag_f64(const double *W, int64_t n_pad, int64_t ldw, int64_t strideW
  * Optional outputs (may be NULL): Kinv (n_pad x ldk upper tiles, batch stride strideK),
  * kinv_diag (q x n_pad: diagonal of K^-1, for leave-one-out, compute_loo :1108-1119).
  * partials: scratch of plmc_grad_scratch_bytes_for(n_pad, q, sizeof element) bytes.
- * fp32 entry point with PLMC_BF16X3 on: the W^T W products run on the bf16 matrix cores from a three-plane bf16 split of W
- * (x = hi + mid + lo exactly; six plane products into two fp32 accumulator levels: error vs fp64 0.3-0.4 x that of the
- * fp32 MFMA chain, profiles/r03_split_numerics.txt); the planes live behind the partials.
+ * fp32 entry point, PLMC_SPLIT != 0: the W^T W products run on the 16-bit matrix cores from a split copy of W (planes
+ * behind the partials; arithmetic as documented at plmc_potrf_ex_f32).
  */
 int plmc_kinv_grad_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW,
                        const float *alpha, const float *X, int n, int d, const float *ell,
@@ -204,6 +219,17 @@ int plmc_kinv_grad_f64(int kind, const double *W, int64_t n_pad, int64_t ldw, in
                        const double *alpha, const double *X, int n, int d, const double *ell,
                        const double *oscale, double *grad, double *Kinv, int64_t ldk, int64_t strideK,
                        double *kinv_diag, void *partials, int q, void *stream);
+/* The same with `eig_lo`: q lower bounds of the smallest eigenvalue of Khat (device pointer; for a GP covariance K + s2 I
+ * the noise variances s2).  With them the fp32 entry point may run its W^T W products as the two-plane fp16 split (see
+ * plmc_potrf_ex_f32); NULL or the plain entry point: three-plane bf16 split.  The fp64 entry point ignores it. */
+int plmc_kinv_grad_ex_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW,
+                          const float *alpha, const float *X, int n, int d, const float *ell,
+                          const float *oscale, double *grad, float *Kinv, int64_t ldk, int64_t strideK,
+                          float *kinv_diag, void *partials, int q, const float *eig_lo, void *stream);
+int plmc_kinv_grad_ex_f64(int kind, const double *W, int64_t n_pad, int64_t ldw, int64_t strideW,
+                          const double *alpha, const double *X, int n, int d, const double *ell,
+                          const double *oscale, double *grad, double *Kinv, int64_t ldk, int64_t strideK,
+                          double *kinv_diag, void *partials, int q, const double *eig_lo, void *stream);
 
 /*
  * Exact (dense) LMC / ICM: Kronecker-structured coregionalisation.
@@ -289,9 +315,8 @@ int plmc_qr_small_f64(const double *A, int m, int n, int64_t lda, double *Q, int
  * share those events); different devices are independent.  The Python layer calls from one thread per process.
  * Dev knobs are environment variables read once per process (PLMC_HALF_TILES, PLMC_GRP, PLMC_KINV_ORDER,
  * PLMC_SERIAL, PLMC_BULK_LDS); plmc_dev_reload_knobs() re-reads them (tests and bench.py change one and reload).  They change
- * schedules; PLMC_GRP also changes the depth of the updates and with it the rounding.  PLMC_BF16X3 selects the arithmetic
- * of the bulk fp32 products (plmc_kinv_grad_f32 and the depth-(128 G) tail / head updates inside plmc_potrf_f32): 1 = split
- * operands on the bf16 matrix cores (bf3_engine.hpp), 0 = v_mfma_f32_16x16x4_f32.  Buffer sizes do not depend on any knob.
+ * schedules; PLMC_GRP also changes the depth of the updates and with it the rounding.  PLMC_SPLIT (0, 2, 3) selects the
+ * arithmetic of the bulk fp32 products (see plmc_potrf_ex_f32).  Buffer sizes do not depend on any knob.
  * plmc_prof_mfma_rate: dense MFMA rate (TFLOP/s) of the current device measured with a bare instruction stream
  * (v_mfma_f32_16x16x4_f32, _f64_16x16x4_f64 or v_mfma_f32_16x16x32_bf16, 4 waves per SIMD, no memory traffic); synchronous; `sink` = caller-owned
  * device scratch of at least 4 * CUs * 256 * sizeof(element) bytes.

@@ -39,7 +39,8 @@ static void load_knobs() {
   g_knobs.serial = getenv("PLMC_SERIAL") && atoi(getenv("PLMC_SERIAL")) != 0;
   g_knobs.kinv_order = o ? atoi(o) : 4;
   g_knobs.bulk_lds = getenv("PLMC_BULK_LDS") ? atoi(getenv("PLMC_BULK_LDS")) : -1;
-  g_knobs.bf16x3 = !getenv("PLMC_BF16X3") || atoi(getenv("PLMC_BF16X3")) != 0;     // default ON (fp32 entry points only)
+  g_knobs.split = getenv("PLMC_SPLIT") ? atoi(getenv("PLMC_SPLIT")) : 2;     // fp32 entry points only
+  if (g_knobs.split != 0 && g_knobs.split != 3) g_knobs.split = 2;
   g_knobs.bulk_streams = getenv("PLMC_BULK_STREAMS") ? atoi(getenv("PLMC_BULK_STREAMS")) : 2;
   g_knobs_loaded = true;
 }

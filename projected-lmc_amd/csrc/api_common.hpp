@@ -45,14 +45,15 @@ struct ProfScope {
 
 // Dev knobs (environment variables), read ONCE per process on first use; plmc_dev_reload_knobs() re-reads them (the
 // tests and bench.py change a knob and reload).  They change schedules; PLMC_GRP also changes the depth of the updates (and
-// with it the rounding), PLMC_BF16X3 selects the arithmetic of the bulk fp32 products.
+// with it the rounding), PLMC_SPLIT selects the arithmetic of the bulk fp32 products.
 struct Knobs {
   double half_tiles;   // PLMC_HALF_TILES: 0 never, 1 always, N > 1 = tile-count threshold (default 640)
   int grp;             // PLMC_GRP: fixed group size of the sweep (default 0 = 8)
   bool serial;         // PLMC_SERIAL: one stream, no look-ahead
   int bulk_lds;        // PLMC_BULK_LDS: extra dynamic LDS bytes per bulk workgroup (caps bulk occupancy); -1 = default by q
-  bool bf16x3;         // PLMC_BF16X3 (default 1): bulk fp32 products (tail / head updates, K^-1) on the bf16 matrix cores from three-plane
-                       // split operands, two accumulator levels (bf3_engine.hpp); 0: v_mfma_f32_16x16x4_f32 everywhere
+  int split;           // PLMC_SPLIT: arithmetic of the bulk fp32 products (tail / head updates, group panel, K^-1): 0 = v_mfma_f32_16x16x4_f32
+                       // everywhere; 3 = three bf16 planes, six products (bf3_engine.hpp SplitB3); 2 (default) = two fp16 planes, three
+                       // products (SplitH2) where the caller gives eigenvalue bounds (plmc_*_ex_f32), SplitB3 otherwise
   int bulk_streams;    // PLMC_BULK_STREAMS: 2 = group panel + head rows on their own helper stream beside the tail, 1 = in front of the tail on the caller's stream
   int kinv_order;      // PLMC_KINV_ORDER: tile order of the gradient kernel (0 XCD-dealt, 1 grid, 4 longest first, 5 = 4 + general epilogue)
 };

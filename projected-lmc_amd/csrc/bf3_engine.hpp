@@ -1,28 +1,33 @@
-// bf3_engine.hpp -- fp32 tile products on the bf16 matrix cores, second engine (round 3).
+// bf3_engine.hpp -- fp32 tile products on the 16-bit matrix cores: the "split engine" (round 3).
 //
-// What it computes.  C[i][j] (+)= sum_k A[k][i] B[k][j] for fp32 operands that were split ONCE into three bf16 planes
-// x = hi + mid + lo (round to nearest even at every level, exact residuals: all 24 significand bits), as six plane
-// products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- into TWO accumulator levels:
-//     level 0:  hi.hi                                  (magnitude of the product itself)
-//     level 1:  lo.hi + hi.lo + mid.mid + mid.hi + hi.mid   (2^-8 of it and below)
-// summed once at the end.  tools/split_numerics_probe.hip (profiles/r03_split_numerics.txt) is why: the error of such a
-// product against fp64 is 0.3-0.4 x that of the v_mfma_f32_16x16x4_f32 chain of the fp32 engine (K = 1024 and 8192;
-// normal, one-signed and wide-range data) and it is the rounding of level 0 alone -- eight or nine plane products give
-// the same digits, a third level changes nothing -- whereas ONE accumulator for all six products (round 2's opt-in)
-// carries 2.5 x the error of two levels (the small products are rounded against the large running sum).  The dropped
-// products mid.lo, lo.mid, lo.lo are below 2^-24 of a product.
+// What it computes.  C[i][j] (+)= sum_k A[k][i] B[k][j] for fp32 operands that were split ONCE into 16-bit planes, as a few
+// plane products on v_mfma_f32_16x16x32_{bf16,f16} with fp32 accumulation into TWO accumulator levels (level 0: the
+// leading product, level 1: everything 2^-8 / 2^-11 of it and below), combined once at the end.  Two split schemes:
+//   SplitB3  x = hi + mid + lo, three bf16 planes (exact: all 24 significand bits), SIX plane products.  bf16 has the fp32
+//            exponent range: works for any data, no scaling.
+//   SplitH2  s x = h0 + 2^-11 h1, two fp16 planes (22 significand bits), THREE plane products: h0.h0 | h1.h0 + h0.h1.
+//            fp16 has a 5-bit exponent, so every operand FAMILY is scaled by a power of two s that puts a rigorous bound of
+//            its magnitude at 2^13 (potrf.hip derives the bounds from the largest diagonal entry and a lower bound of the
+//            smallest eigenvalue, i.e. the noise); the product is unscaled in the epilogue (exact).
+// tools/split_numerics_probe.hip (profiles/r03_split_numerics.txt) is why: against fp64 either product has 0.3-0.45 x the
+// error of the v_mfma_f32_16x16x4_f32 chain of the fp32 engine (K = 1024 and 8192; normal, one-signed, wide-range data and
+// the cancelling product of the group panel) -- the fp32 chain rounds its running sum K times, the split engines K / 32
+// times, and that rounding, not the operand precision, is what the error consists of: eight or nine bf16 plane products
+// or a third fp16 plane give the same digits.  ONE accumulator for all products (round 2's opt-in) carries 2.5 x the
+// error of two levels (the small products are rounded against the large running sum).
 //
 // How.  A workgroup of 512 threads = 8 waves owns a 256 x 128 macro tile (two 128 x 128 tiles of one block column: the
 // rows ib, ib + 1 share the B strip), each wave a 64 x 64 block of it as 4 x 4 MFMA tiles -- the accumulator layout of the
 // fp32 engine (gemm_core.hpp), so tile_writeback and the gradient epilogues are reused per half.  Operand planes live in
 // HBM in "k8" order,
 //     P[k / 8][plane][column][k % 8]        (16 bytes = the 8 contraction values one MFMA lane needs),
-// so that (a) a stage of 32 contraction rows of a tile is 12 runs of 2-4 KB, copied to LDS by LDS-DMA
+// so that (a) a stage of 32 contraction rows of a tile is a few runs of 2-4 KB, copied to LDS by LDS-DMA
 // (buffer_load_dwordx4 ... lds: no staging registers, no ds_write, one 1 KB piece per wave instruction) and (b) an MFMA
 // fragment is ONE conflict-free ds_read_b128 per lane (lanes 16 g .. 16 g + 15 read 256 contiguous bytes of k-group g):
-// no transposing reads, no swizzle.  Two LDS stages of 72 KB (A: 3 planes x 16 KB, B: 3 x 8 KB); per stage and wave
-// 9 DMA pieces, 24 fragment reads and 96 MFMAs; one barrier per stage: the DMA of stage s + 1 is issued right after the
-// barrier that ends the reads of stage s - 1 and lands while stage s is multiplied.
+// no transposing reads, no swizzle.  Two LDS stages (SplitB3: 72 KB each, SplitH2: 48 KB); one barrier per stage: the DMA
+// of stage s + 1 is issued right after the barrier that ends the reads of stage s - 1 and lands while stage s is multiplied.
+// Alone on the GPU (tools/bf3v2_probe.hip, depth-1024 update tiles): fp32 engine 127 TF, SplitB3 223 TF, SplitH2 353 TF
+// fp32-equivalent.
 #pragma once
 #include "gemm_core.hpp"
 
@@ -33,82 +38,117 @@ constexpr int B3_K = 32;                                   // contraction rows p
 constexpr int B3_AW = 256, B3_BW = 128;                    // macro tile: A side (rows of C) x B side (columns of C)
 constexpr int B3_A_PLANE = (B3_K / 8) * B3_AW * 16;        // bytes of one A plane of a stage: [4 k-groups][256][16 B]
 constexpr int B3_B_PLANE = (B3_K / 8) * B3_BW * 16;
-constexpr int B3_STAGE = 3 * (B3_A_PLANE + B3_B_PLANE);    // 73 728
-constexpr int B3_LDS_BYTES = 2 * B3_STAGE;                 // 147 456: one workgroup per CU
 constexpr int B3_WB_BYTES = 64 * 132 * 4;                  // staging of tile_writeback, per 128 x 128 half
 
 typedef __bf16 b3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 b3_f16x8 __attribute__((ext_vector_type(8)));
 typedef short b3_s16x8 __attribute__((ext_vector_type(8)));
 
+struct SplitB3 {
+  static constexpr int NPL = 3;
+  static constexpr float LEVEL1 = 1.0f;                    // weight of the level-1 accumulator in the final sum
+  typedef b3_bf16x8 frag_t;
+  static __device__ __forceinline__ f32x4 mfma(frag_t a, frag_t b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void split(float v, short (&o)[3]) {
+    const __bf16 a = (__bf16)v;
+    const float r1 = v - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const __bf16 c = (__bf16)(r1 - (float)b);
+    o[0] = __builtin_bit_cast(short, a); o[1] = __builtin_bit_cast(short, b); o[2] = __builtin_bit_cast(short, c);
+  }
+};
+struct SplitH2 {
+  static constexpr int NPL = 2;
+  static constexpr float LEVEL1 = 1.0f / 2048.0f;
+  typedef b3_f16x8 frag_t;
+  static __device__ __forceinline__ f32x4 mfma(frag_t a, frag_t b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void split(float v, short (&o)[2]) {      // v is already scaled into the fp16 range
+    const _Float16 a = (_Float16)v;
+    const _Float16 b = (_Float16)((v - (float)a) * 2048.0f);
+    o[0] = __builtin_bit_cast(short, a); o[1] = __builtin_bit_cast(short, b);
+  }
+};
+template <class S> constexpr int b3_stage_bytes() { return S::NPL * (B3_A_PLANE + B3_B_PLANE); }    // 73 728 / 49 152
+template <class S> constexpr int b3_lds_bytes() { return 2 * b3_stage_bytes<S>() > 2 * B3_WB_BYTES ? 2 * b3_stage_bytes<S>() : 2 * B3_WB_BYTES; }
+
 // element (k, plane, column) of a k8-ordered plane buffer with `ld` columns, in 16-bit elements
-__host__ __device__ inline int64_t b3_index(int64_t k, int plane, int64_t col, int64_t ld) {
-  return (((k >> 3) * 3 + plane) * ld + col) * 8 + (k & 7);
+template <class S> __host__ __device__ inline int64_t b3_index(int64_t k, int plane, int64_t col, int64_t ld) {
+  return (((k >> 3) * S::NPL + plane) * ld + col) * 8 + (k & 7);
 }
 // 16-bit elements of a plane buffer of `rows` contraction rows (a multiple of 8) and `ld` columns
-__host__ __device__ inline int64_t b3_elems(int64_t rows, int64_t ld) { return rows * 3 * ld; }
+template <class S> __host__ __device__ inline int64_t b3_elems(int64_t rows, int64_t ld) { return rows * S::NPL * ld; }
 
-// Eight contraction rows x four columns of fp32 -> the three planes' 16-byte groups (one per column and plane).
-// x[r][c]: row r (0..7) of the k8 group, column c (0..3).  `dst` = &P[k8][0][col0][0]; plane stride = ld * 8 elements.
-__device__ __forceinline__ void b3_split_store(const float (&x)[8][4], unsigned short *dst, int64_t ld) {
+// Power-of-two scale that puts `bound` (> 0) at 2^13: fp16 overflows at 2^16, so a bound that fp32 rounding exceeds by
+// less than 8 x is still safe; values down to 2^-27 of the bound keep their 22 bits.
+__host__ __device__ inline float b3_scale_for(float bound) {
+  int e;
+  (void)frexpf(bound, &e);                                  // bound = f 2^e, f in [0.5, 1)
+  return ldexpf(1.0f, 13 - e);
+}
+
+// Eight contraction rows x four columns of fp32 -> the planes' 16-byte groups (one per column and plane).
+// x[r][c]: row r (0..7) of the k8 group, column c (0..3); every value is multiplied by `scale` first (SplitB3: 1).
+// `dst` = &P[k8][0][col0][0]; plane stride = ld * 8 elements.
+template <class S>
+__device__ __forceinline__ void b3_split_store(const float (&x)[8][4], unsigned short *dst, int64_t ld, float scale) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    b3_s16x8 h, m, l;
+    b3_s16x8 pl[S::NPL];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const float v = x[r][c];
-      const __bf16 a = (__bf16)v;
-      const float r1 = v - (float)a;
-      const __bf16 b = (__bf16)r1;
-      const __bf16 cc = (__bf16)(r1 - (float)b);
-      h[r] = __builtin_bit_cast(short, a);
-      m[r] = __builtin_bit_cast(short, b);
-      l[r] = __builtin_bit_cast(short, cc);
+      short o[S::NPL];
+      S::split(x[r][c] * scale, o);
+#pragma unroll
+      for (int p = 0; p < S::NPL; ++p) pl[p][r] = o[p];
     }
-    *reinterpret_cast<b3_s16x8 *>(dst + c * 8) = h;
-    *reinterpret_cast<b3_s16x8 *>(dst + ld * 8 + c * 8) = m;
-    *reinterpret_cast<b3_s16x8 *>(dst + 2 * ld * 8 + c * 8) = l;
+#pragma unroll
+    for (int p = 0; p < S::NPL; ++p) *reinterpret_cast<b3_s16x8 *>(dst + (int64_t)p * ld * 8 + c * 8) = pl[p];
   }
 }
 
-// One 128 x 128 fp32 block (rows = contraction index, leading dimension lds) -> planes.  256 threads; thread = one
-// k8 group x four columns per pass (8 loads of 16 bytes, 12 stores of 16 bytes; whole 512-byte rows / 64-byte runs).
+// One 128 x 128 fp32 block (rows = contraction index, leading dimension lds_) -> planes.  256 threads; thread = one
+// k8 group x four columns per pass (8 loads of 16 bytes, 4 NPL stores of 16 bytes; whole 512-byte rows / 64-byte runs).
 // `P` points at element (k = first row of the block, plane 0, first column of the block).  COPY: also write the block
-// to D (leading dimension ldd): the panel copy of the sweep does both in one pass.
-template <bool COPY>
-__device__ __forceinline__ void b3_split_block(const float *__restrict__ S, int64_t lds_, unsigned short *__restrict__ P, int64_t ld, float *D,
-                                               int64_t ldd, int tid) {
+// to D (leading dimension ldd).
+template <class S, bool COPY>
+__device__ __forceinline__ void b3_split_block(const float *__restrict__ Sp, int64_t lds_, unsigned short *__restrict__ P, int64_t ld, float scale,
+                                               float *D, int64_t ldd, int tid) {
 #pragma unroll 1
   for (int w = tid; w < 16 * 32; w += NTHREADS) {
     const int k8 = w >> 5, c4 = (w & 31) * 4;
     float x[8][4];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const float4 v = *reinterpret_cast<const float4 *>(S + (int64_t)(k8 * 8 + r) * lds_ + c4);
+      const float4 v = *reinterpret_cast<const float4 *>(Sp + (int64_t)(k8 * 8 + r) * lds_ + c4);
       x[r][0] = v.x; x[r][1] = v.y; x[r][2] = v.z; x[r][3] = v.w;
       if (COPY) *reinterpret_cast<float4 *>(D + (int64_t)(k8 * 8 + r) * ldd + c4) = v;
     }
-    b3_split_store(x, P + ((int64_t)k8 * 3 * ld + c4) * 8, ld);
+    b3_split_store<S>(x, P + ((int64_t)k8 * S::NPL * ld + c4) * 8, ld, scale);
   }
 }
 
 // acc0 / acc1 += the two levels of  sum_{k < K} A[k][a-columns]^T B[k][b-columns]  for this wave's 64 x 64 block.
 //   Ap: plane buffer at (k = first row of the K range, plane 0, first of the 256 A columns), lda_ columns per plane row;
-//   Bp: likewise, first of the 128 B columns, ldb_ columns;  K % 64 == 0;  lds: B3_LDS_BYTES, 16-byte aligned, the kernel's
-//   ONLY __shared__ object (a second one makes hipcc drain the DMA before every fragment read).
+//   Bp: likewise, first of the 128 B columns, ldb_ columns;  K % 64 == 0;  lds: b3_lds_bytes<S>(), 16-byte aligned, the
+//   kernel's ONLY __shared__ object (a second one makes hipcc drain the DMA before every fragment read).
 // All 512 threads must call it; ends with a barrier (LDS free for the epilogue).
+template <class S>
 __device__ __forceinline__ void b3_mainloop(Acc<float> &acc0, Acc<float> &acc1, const unsigned short *__restrict__ Ap, int64_t lda_,
                                             const unsigned short *__restrict__ Bp, int64_t ldb_, int K, unsigned char *lds) {
+  constexpr int NPL = S::NPL, STAGE = b3_stage_bytes<S>();
+  typedef typename S::frag_t frag_t;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave 0..7, provably uniform (DMA destinations are scalar)
   const int half = w >> 2, wm = (w >> 1) & 1, wn = w & 1;
-  // ---- DMA plan of this wave: pieces i = w + 8 j of the 72 per stage.  j = 0..5: A, plane j >> 1, k-group (w >> 2) + 2 (j & 1),
-  // columns 64 (w & 3) ..; j = 6..8: B, plane j - 6, k-group (w >> 1) & 3, columns 64 (w & 1) ..
-  const unsigned RSA = (unsigned)(3 * lda_ * 16), RSB = (unsigned)(3 * ldb_ * 16);   // bytes per k8 row (all planes)
-  const unsigned PLA = (unsigned)(lda_ * 16), PLB = (unsigned)(ldb_ * 16);           // bytes per plane inside a k8 row
+  // ---- DMA plan of this wave: per plane 16 A pieces (k-group, 64-column segment) and 8 B pieces, i.e. per wave and plane
+  // two A pieces (k-groups (w >> 2) and (w >> 2) + 2, columns 64 (w & 3) ..) and one B piece (k-group (w >> 1) & 3,
+  // columns 64 (w & 1) ..)
+  const unsigned RSA = (unsigned)(NPL * lda_ * 16), RSB = (unsigned)(NPL * ldb_ * 16);   // bytes per k8 row (all planes)
+  const unsigned PLA = (unsigned)(lda_ * 16), PLB = (unsigned)(ldb_ * 16);               // bytes per plane inside a k8 row
   const unsigned gA0 = (unsigned)(w >> 2) * RSA + (unsigned)(w & 3) * 1024u;
   const unsigned gB0 = (unsigned)((w >> 1) & 3) * RSB + (unsigned)(w & 1) * 1024u;
   const unsigned lA0 = (unsigned)(((w >> 2) * B3_AW + (w & 3) * 64) * 16);
-  const unsigned lB0 = (unsigned)(3 * B3_A_PLANE + (((w >> 1) & 3) * B3_BW + (w & 1) * 64) * 16);
+  const unsigned lB0 = (unsigned)(NPL * B3_A_PLANE + (((w >> 1) & 3) * B3_BW + (w & 1) * 64) * 16);
   const unsigned voff = (unsigned)lane * 16u;
   const char *baseA = reinterpret_cast<const char *>(Ap), *baseB = reinterpret_cast<const char *>(Bp);
   const int64_t stepA = (int64_t)(B3_K / 8) * RSA, stepB = (int64_t)(B3_K / 8) * RSB;
@@ -116,13 +156,13 @@ __device__ __forceinline__ void b3_mainloop(Acc<float> &acc0, Acc<float> &acc1, 
   auto issue = [&](int buf) {
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(baseA), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(baseB), 0, 0x7fffffff, 0x00020000);
-    unsigned char *sb = lds + buf * B3_STAGE;
+    unsigned char *sb = lds + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
+    for (int j = 0; j < 2 * NPL; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void *)(sb + lA0 + (j >> 1) * B3_A_PLANE + (j & 1) * (2 * B3_AW * 16)), 16, voff,
-                                           gA0 + (unsigned)(j & 1) * 2u * RSA + (unsigned)(j >> 1) * PLA, 0, 0);
+                                               gA0 + (unsigned)(j & 1) * 2u * RSA + (unsigned)(j >> 1) * PLA, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < NPL; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void *)(sb + lB0 + j * B3_B_PLANE), 16, voff, gB0 + (unsigned)j * PLB, 0, 0);
     baseA += stepA;
     baseB += stepB;
@@ -130,37 +170,48 @@ __device__ __forceinline__ void b3_mainloop(Acc<float> &acc0, Acc<float> &acc1, 
   // ---- fragment addresses: lane (kg = lane >> 4, fr = lane & 15) reads 16 bytes of k-group kg, row / column .. + fr
   const int kg = lane >> 4, fr = lane & 15;
   const unsigned aA = (unsigned)((kg * B3_AW + half * 128 + wm * 64 + fr) * 16);
-  const unsigned aB = (unsigned)(3 * B3_A_PLANE + (kg * B3_BW + wn * 64 + fr) * 16);
+  const unsigned aB = (unsigned)(NPL * B3_A_PLANE + (kg * B3_BW + wn * 64 + fr) * 16);
   auto compute = [&](int buf) {
-    const unsigned char *sa = lds + buf * B3_STAGE + aA, *sb = lds + buf * B3_STAGE + aB;
-    auto fa = [&](int plane, b3_bf16x8 (&f)[4]) {
+    const unsigned char *sa = lds + buf * STAGE + aA, *sb = lds + buf * STAGE + aB;
+    auto fa = [&](int plane, frag_t (&f)[4]) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) f[t] = *reinterpret_cast<const b3_bf16x8 *>(sa + plane * B3_A_PLANE + t * 256);
+      for (int t = 0; t < 4; ++t) f[t] = *reinterpret_cast<const frag_t *>(sa + plane * B3_A_PLANE + t * 256);
     };
-    auto fb = [&](int plane, b3_bf16x8 (&f)[4]) {
+    auto fb = [&](int plane, frag_t (&f)[4]) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) f[t] = *reinterpret_cast<const b3_bf16x8 *>(sb + plane * B3_B_PLANE + t * 256);
+      for (int t = 0; t < 4; ++t) f[t] = *reinterpret_cast<const frag_t *>(sb + plane * B3_B_PLANE + t * 256);
     };
-    auto mm = [&](Acc<float> &acc, const b3_bf16x8 (&x)[4], const b3_bf16x8 (&y)[4]) {
+    auto mm = [&](Acc<float> &acc, const frag_t (&x)[4], const frag_t (&y)[4]) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc.v[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[mt], y[nt], acc.v[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < 4; ++nt) acc.v[mt][nt] = S::mfma(x[mt], y[nt], acc.v[mt][nt]);
     };
     // small products first; every fragment is read once
-    b3_bf16x8 bh[4], bx[4], ax[4], ay[4];
-    fb(0, bh);
-    fa(2, ax);
-    mm(acc1, ax, bh);               // lo . hi
-    fa(1, ay);
-    mm(acc1, ay, bh);               // mid . hi
-    fb(1, bx);
-    mm(acc1, ay, bx);               // mid . mid
-    fa(0, ax);
-    mm(acc1, ax, bx);               // hi . mid
-    fb(2, bx);
-    mm(acc1, ax, bx);               // hi . lo
-    mm(acc0, ax, bh);               // hi . hi
+    if constexpr (NPL == 3) {
+      frag_t bh[4], bx[4], ax[4], ay[4];
+      fb(0, bh);
+      fa(2, ax);
+      mm(acc1, ax, bh);               // lo . hi
+      fa(1, ay);
+      mm(acc1, ay, bh);               // mid . hi
+      fb(1, bx);
+      mm(acc1, ay, bx);               // mid . mid
+      fa(0, ax);
+      mm(acc1, ax, bx);               // hi . mid
+      fb(2, bx);
+      mm(acc1, ax, bx);               // hi . lo
+      mm(acc0, ax, bh);               // hi . hi
+    } else {
+      frag_t b0[4], b1[4], a0[4], a1[4];
+      fb(0, b0);
+      fa(1, a1);
+      mm(acc1, a1, b0);               // h1 . h0
+      fa(0, a0);
+      fb(1, b1);
+      mm(acc1, a0, b1);               // h0 . h1
+      mm(acc0, a0, b0);               // h0 . h0
+    }
   };
   const int nst = K / B3_K;                                        // even
   issue(0);
@@ -176,15 +227,26 @@ __device__ __forceinline__ void b3_mainloop(Acc<float> &acc0, Acc<float> &acc1, 
   __syncthreads();
 }
 
+// acc0 <- (acc0 + LEVEL1 acc1) * unscale   (unscale = 1 / (scale of the A family x scale of the B family); SplitB3: 1)
+template <class S> __device__ __forceinline__ void b3_combine(Acc<float> &acc0, const Acc<float> &acc1, float unscale) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if constexpr (S::NPL == 3) acc0.v[a][b] += acc1.v[a][b];
+      else acc0.v[a][b] = (acc0.v[a][b] + acc1.v[a][b] * S::LEVEL1) * unscale;
+    }
+}
+
 // Epilogue of one 128 x 128 half of the macro tile: tile_writeback (gemm_core.hpp) for fp32 plus, with PLANES, the FINAL
-// values of the tile also as k8-ordered bf16 planes -- the next consumer's operand, written while the tile is still in
-// LDS instead of by a separate split pass.  `Pp` = plane buffer at (k = the tile's first row, plane 0, the tile's first
-// column), `pld` its columns.  Per 64-row pass the finals go back into the staging area (for the read-modify-write modes),
-// then every thread splits 8 rows x 4 columns.  tid = threadIdx.x & 255; `live` as in tile_writeback; `planes_live`: this half
-// also writes planes (both wave-uniform per half).
-template <int MODE, bool PLANES>
+// values of the tile (times `pscale`) also as k8-ordered planes -- the next consumer's operand, written while the tile is
+// still in LDS instead of by a separate split pass.  `Pp` = plane buffer at (k = the tile's first row, plane 0, the tile's
+// first column), `pld` its columns.  Per 64-row pass the finals go back into the staging area (for the read-modify-write
+// modes), then every thread splits 8 rows x 4 columns.  tid = threadIdx.x & 255; `live` as in tile_writeback;
+// `planes_live`: this half also writes planes (both wave-uniform per half).
+template <class S, int MODE, bool PLANES>
 __device__ __forceinline__ void b3_writeback(const Acc<float> &acc, float *Cg, int64_t ldc, float *smem, int tid, bool live,
-                                             unsigned short *Pp = nullptr, int64_t pld = 0, bool planes_live = true) {
+                                             unsigned short *Pp = nullptr, int64_t pld = 0, bool planes_live = true, float pscale = 1.0f) {
   if constexpr (!PLANES) {
     tile_writeback<float, MODE>(acc, Cg, ldc, smem, tid, live);
   } else {
@@ -233,7 +295,7 @@ __device__ __forceinline__ void b3_writeback(const Acc<float> &acc, float *Cg, i
           const f32x4 v = *reinterpret_cast<const f32x4 *>(smem + (k8 * 8 + r) * LDW + c4);
           x[r][0] = v[0]; x[r][1] = v[1]; x[r][2] = v[2]; x[r][3] = v[3];
         }
-        b3_split_store(x, Pp + ((int64_t)(half * 8 + k8) * 3 * pld + c4) * 8, pld);
+        b3_split_store<S>(x, Pp + ((int64_t)(half * 8 + k8) * S::NPL * pld + c4) * 8, pld, pscale);
       }
     }
   }

@@ -142,6 +142,53 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
   else tile_writeback<T, WB_SUB, MT>(acc, C, ldc, smem);               // C -= P^T P
 }
 
+// ---- scales of the split engine's operand families (bf3_engine.hpp).  Per latent eight floats in the Vd scratch:
+enum { SC_SU = 0, SC_SW = 1, SC_RU = 2, SC_RW = 3, SC_N = 8 };
+//   SU solved rows, U columns:      |U_kj| <= sqrt(A_jj) <= sqrt(D),  D = largest diagonal entry of the input
+//   SW solved rows, W columns, and the inverse triangle Vgg:   |W_ij| <= ||U^-1||_2 = 1 / sqrt(lambda_min)
+//   RU raw rows (before their panel solve), U columns: entries of Schur complements, <= D
+//   RW raw rows, W columns:  -U[<g, R]^T W[<g, c],  <= ||U[:, j]||_2 ||W||_2 <= sqrt(D / lambda_min)
+// lambda_min is bounded below by the caller's `eig_lo` (the noise variance of a GP covariance) -- and by the smallest
+// diagonal entry, which brings in the identity padding of the rows beyond n (eigenvalue 1, whatever the noise).  SplitB3
+// needs no scales (all 1).  grid (q).
+template <class S>
+__global__ __launch_bounds__(NTHREADS) void k_split_scales(const float *__restrict__ A, int64_t n_pad, int64_t lda, int64_t strideA,
+                                                           const float *__restrict__ eig_lo, float *__restrict__ sc, int64_t sc_stride) {
+  const int lat = blockIdx.x;
+  float *o = sc + (int64_t)lat * sc_stride;
+  if constexpr (S::NPL == 3) {
+    if (threadIdx.x < SC_N) o[threadIdx.x] = 1.0f;
+  } else {
+    __shared__ float red[NTHREADS], redm[NTHREADS];
+    float d = 0.0f, dm = 3.0e38f;
+    for (int64_t i = threadIdx.x; i < n_pad; i += NTHREADS) {
+      const float v = A[(int64_t)lat * strideA + i * lda + i];
+      d = fmaxf(d, v);
+      dm = fminf(dm, v);
+    }
+    red[threadIdx.x] = d;
+    redm[threadIdx.x] = dm;
+    __syncthreads();
+    for (int k = NTHREADS / 2; k > 0; k >>= 1) {
+      if ((int)threadIdx.x < k) {
+        red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + k]);
+        redm[threadIdx.x] = fminf(redm[threadIdx.x], redm[threadIdx.x + k]);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const float D = red[0] > 0.0f ? red[0] : 1.0f;
+      float lam = fminf(eig_lo[lat], redm[0]);             // (lambda_min <= every diagonal entry: still a lower bound)
+      if (!(lam > 1e-12f * D)) lam = 1e-12f * D;          // no usable bound: assume a condition number of 1e12
+      o[SC_SU] = b3_scale_for(sqrtf(D));
+      o[SC_SW] = b3_scale_for(1.0f / sqrtf(lam));
+      o[SC_RU] = b3_scale_for(D);
+      o[SC_RW] = b3_scale_for(sqrtf(D / lam));
+      o[4] = D; o[5] = lam; o[6] = 0.0f; o[7] = 0.0f;
+    }
+  }
+}
+
 // fp32, PLMC_BF16X3 (the fp32 default): the bulk trailing updates (tail, head rows) with their depth-(128 G) products on the
 // bf16 matrix cores (bf3_engine.hpp).  A workgroup of 512 threads takes the macro tile (block rows ib, ib + 1) x (column tile
 // bx).  The operands are the panel rows of the current group, which k_gpanel_copy / k_wtri_planes also write as k8-ordered
@@ -150,13 +197,13 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
 // Block rows ib < raw_end are the NEXT group's rows and this is their last update: their final values also go, as planes,
 // into `Praw` (row 128 (ib - ib0) .., same columns) -- the right-hand side of the next group panel (k_gpanel_bf3).
 // grid (nU + Taug + nW, (nrows + 1) / 2, q).
-template <int ROLE>
+template <class S, int ROLE>
 __global__ __launch_bounds__(B3_NT, 2) void k_update_bf3(float *A, int64_t lda, int64_t strideA, int ib0, int nrows, int r_lo, int r_hi,
                                                          ColMap<float> cm, int skip_ib, int skip_jb, const unsigned short *__restrict__ Pl,
                                                          int64_t pl_lat_stride, int64_t wcol0, unsigned short *__restrict__ Praw,
-                                                         int64_t praw_lat_stride, int raw_end) {
+                                                         int64_t praw_lat_stride, int raw_end, const float *__restrict__ sc, int64_t sc_stride) {
   if (ROLE == 3) __builtin_amdgcn_s_setprio(2);
-  __shared__ __align__(16) unsigned char lds[B3_LDS_BYTES];
+  __shared__ __align__(16) unsigned char lds[b3_lds_bytes<S>()];
   const int bx = blockIdx.x, ibm = ib0 + 2 * (int)blockIdx.y, lat = blockIdx.z;
   int kr0 = r_lo * NB, depth = (r_hi - r_lo + 1) * NB;
   bool first = false;
@@ -164,12 +211,14 @@ __global__ __launch_bounds__(B3_NT, 2) void k_update_bf3(float *A, int64_t lda, 
   float *Cb = Al;
   int64_t ldc = lda, col0, colp;                                       // colp: column of the B operand in the plane buffer
   bool v0 = true, v1 = ibm + 1 < ib0 + nrows;                          // which halves have a tile
+  const float *scl = sc + (int64_t)lat * sc_stride;
+  float sB = scl[SC_SU], sRaw = scl[SC_RU];                             // scale of the B operand's family / of this tile's raw planes
   if (bx < cm.nU) {
     const int jb = cm.u0 + bx;
     v0 = jb >= ibm && !(ibm < skip_ib && jb < skip_jb);
     v1 = v1 && jb >= ibm + 1 && !(ibm + 1 < skip_ib && jb < skip_jb);
     col0 = colp = (int64_t)jb * NB;
-  } else if (bx < cm.nU + cm.Taug) {
+  } else if (bx < cm.nU + cm.Taug) {                                   // (SplitB3 only: SplitH2 launches carry no augmented tiles)
     col0 = colp = cm.n_pad + (int64_t)(bx - cm.nU) * NB;
   } else {
     const int cb = cm.w0 + bx - cm.nU - cm.Taug;
@@ -177,28 +226,27 @@ __global__ __launch_bounds__(B3_NT, 2) void k_update_bf3(float *A, int64_t lda, 
     ldc = cm.ldw;
     col0 = (int64_t)cb * NB;
     colp = wcol0 + col0;
+    sB = scl[SC_SW];
+    sRaw = scl[SC_RW];
     if (cb >= r_lo) { first = true; kr0 = cb * NB; depth = (r_hi - cb + 1) * NB; }
   }
   if (!v0 && !v1) return;
   Acc<float> acc0, acc1;
   acc0.zero();
   acc1.zero();
-  const unsigned short *Pr = Pl + (int64_t)lat * pl_lat_stride + b3_index(kr0 - r_lo * NB, 0, 0, lda);
-  b3_mainloop(acc0, acc1, Pr + (int64_t)ibm * NB * 8, lda, Pr + colp * 8, lda, depth, lds);
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc0.v[a][b] += acc1.v[a][b];
+  const unsigned short *Pr = Pl + (int64_t)lat * pl_lat_stride + b3_index<S>(kr0 - r_lo * NB, 0, 0, lda);
+  b3_mainloop<S>(acc0, acc1, Pr + (int64_t)ibm * NB * 8, lda, Pr + colp * 8, lda, depth, lds);
+  b3_combine<S>(acc0, acc1, 1.0f / (scl[SC_SU] * sB));
   const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
   float *C = Cb + (int64_t)(ibm + half) * NB * ldc + col0;
   float *stg = reinterpret_cast<float *>(lds + half * B3_WB_BYTES);
   const bool live = half ? v1 : v0;
   const int tid = (int)threadIdx.x & 255;
   if (Praw && ibm < raw_end) {              // uniform per workgroup; a half at or beyond raw_end writes no planes
-    unsigned short *Pp = Praw + (int64_t)lat * praw_lat_stride + b3_index((int64_t)(ibm + half - ib0) * NB, 0, colp, lda);
+    unsigned short *Pp = Praw + (int64_t)lat * praw_lat_stride + b3_index<S>((int64_t)(ibm + half - ib0) * NB, 0, colp, lda);
     const bool pl = ibm + half < raw_end;
-    if (first) b3_writeback<WB_STORE_NEG, true>(acc0, C, ldc, stg, tid, live, Pp, lda, pl);
-    else b3_writeback<WB_SUB, true>(acc0, C, ldc, stg, tid, live, Pp, lda, pl);
+    if (first) b3_writeback<S, WB_STORE_NEG, true>(acc0, C, ldc, stg, tid, live, Pp, lda, pl, sRaw);
+    else b3_writeback<S, WB_SUB, true>(acc0, C, ldc, stg, tid, live, Pp, lda, pl, sRaw);
     return;
   }
   if (first) tile_writeback<float, WB_STORE_NEG>(acc0, C, ldc, stg, tid, live);   // first touch of a W tile
@@ -258,10 +306,10 @@ __global__ __launch_bounds__(NTHREADS, (sizeof(T) == 8 || HEAD ? 2 : 4)) void k_
 }
 
 // Panel buffer -> factor buffer (block row g0 + i, column strip t of the column map).  grid (tiles, G, q); HBM-bound.
-template <typename T>
+template <typename T, class S = SplitB3>
 __global__ __launch_bounds__(NTHREADS) void k_gpanel_copy(T *A, int64_t lda, int64_t strideA, int g0, ColMap<T> cm, const T *__restrict__ Pb,
                                                           int64_t ldp, int64_t strideP, unsigned short *__restrict__ Pl, int64_t pl_lat_stride,
-                                                          int64_t wcol0) {
+                                                          int64_t wcol0, const float *__restrict__ sc, int64_t sc_stride) {
   using vec_t = typename Traits<T>::vec_t;
   constexpr int EPV = Traits<T>::EPV, CPR = NB / EPV;
   const int lat = blockIdx.z, t = blockIdx.x, i = blockIdx.y;
@@ -274,16 +322,17 @@ __global__ __launch_bounds__(NTHREADS) void k_gpanel_copy(T *A, int64_t lda, int
     colp = wcol0 + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
     D = cm.W + (int64_t)lat * cm.strideW + (int64_t)(g0 + i) * NB * ldd + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
   }
-  const T *S = Pb + (int64_t)lat * strideP + (int64_t)i * NB * ldp + (int64_t)t * NB;
+  const T *Src = Pb + (int64_t)lat * strideP + (int64_t)i * NB * ldp + (int64_t)t * NB;
   if constexpr (sizeof(T) == 4) {
-    if (Pl) {                                              // PLMC_BF16X3: the finished rows also as k8-ordered bf16 planes
-      b3_split_block<true>(S, ldp, Pl + (int64_t)lat * pl_lat_stride + b3_index((int64_t)i * NB, 0, colp, lda), lda, D, ldd, threadIdx.x);
+    if (Pl) {                                              // split engine: the finished rows also as k8-ordered planes
+      const float scale = sc[(int64_t)lat * sc_stride + (t < cm.nU + cm.Taug ? SC_SU : SC_SW)];
+      b3_split_block<S, true>(Src, ldp, Pl + (int64_t)lat * pl_lat_stride + b3_index<S>((int64_t)i * NB, 0, colp, lda), lda, scale, D, ldd, threadIdx.x);
       return;
     }
   }
   for (int c = threadIdx.x; c < NB * CPR; c += NTHREADS) {
     const int r = c / CPR, col = (c % CPR) * EPV;
-    *reinterpret_cast<vec_t *>(D + (int64_t)r * ldd + col) = *reinterpret_cast<const vec_t *>(S + (int64_t)r * ldp + col);
+    *reinterpret_cast<vec_t *>(D + (int64_t)r * ldd + col) = *reinterpret_cast<const vec_t *>(Src + (int64_t)r * ldp + col);
   }
 }
 
@@ -320,49 +369,58 @@ __global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, i
 // PLMC_BF16X3 (fp32): the group's inverse triangle W[g0 + i][g0 + k] (k <= i < G, already in the factor buffer's W columns:
 // k_vtrans) as k8-ordered bf16 planes of the rolling buffer (rows 128 i .., column wcol0 + 128 (g0 + k)): the operands of the
 // first-touch W tiles of the tail / head updates.  Off the chain's stream.  grid (G (G + 1) / 2, q).
+template <class S>
 __global__ __launch_bounds__(NTHREADS) void k_wtri_planes(const float *__restrict__ WA, int64_t lda, int64_t strideA, int g0,
-                                                          unsigned short *__restrict__ Pl, int64_t pl_lat_stride, int64_t wcol0) {
+                                                          unsigned short *__restrict__ Pl, int64_t pl_lat_stride, int64_t wcol0,
+                                                          const float *__restrict__ sc, int64_t sc_stride) {
   const int lat = blockIdx.y;
   int i = 0, k = (int)blockIdx.x;
   while (k > i) { k -= i + 1; ++i; }
-  b3_split_block<false>(WA + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + (int64_t)(g0 + k) * NB, lda,
-                        Pl + (int64_t)lat * pl_lat_stride + b3_index((int64_t)i * NB, 0, wcol0 + (int64_t)(g0 + k) * NB, lda), lda, nullptr, 0,
-                        threadIdx.x);
+  b3_split_block<S, false>(WA + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + (int64_t)(g0 + k) * NB, lda,
+                           Pl + (int64_t)lat * pl_lat_stride + b3_index<S>((int64_t)i * NB, 0, wcol0 + (int64_t)(g0 + k) * NB, lda), lda,
+                           sc[(int64_t)lat * sc_stride + SC_SW], nullptr, 0, threadIdx.x);
 }
 
 // PLMC_BF16X3 (fp32): Vgg = Ugg^-1 (upper, K-major, the group scratch k_vtrans wrote) as k8-ordered planes with 128 GMAX
 // columns, the A operand of k_gpanel_bf3.  Blocks below the diagonal (k > i) are written as zeros: a macro row of the
 // panel product runs both of its block rows over the depth of the second.  grid (GMAX * GMAX, q).
+template <class S>
 __global__ __launch_bounds__(NTHREADS) void k_vg_planes(const float *__restrict__ Vg, int64_t strideG, int G, unsigned short *__restrict__ VgP,
-                                                        int64_t vgp_lat_stride) {
+                                                        int64_t vgp_lat_stride, const float *__restrict__ sc, int64_t sc_stride) {
   const int lat = blockIdx.y, k = (int)blockIdx.x / GMAX, i = (int)blockIdx.x % GMAX;
-  unsigned short *P = VgP + (int64_t)lat * vgp_lat_stride + b3_index((int64_t)k * NB, 0, (int64_t)i * NB, GMAX * NB);
+  unsigned short *P = VgP + (int64_t)lat * vgp_lat_stride + b3_index<S>((int64_t)k * NB, 0, (int64_t)i * NB, GMAX * NB);
   if (k <= i && i < G) {
-    b3_split_block<false>(Vg + (int64_t)lat * strideG + (int64_t)k * NB * LDG + (int64_t)i * NB, LDG, P, GMAX * NB, nullptr, 0, threadIdx.x);
+    b3_split_block<S, false>(Vg + (int64_t)lat * strideG + (int64_t)k * NB * LDG + (int64_t)i * NB, LDG, P, GMAX * NB,
+                             sc[(int64_t)lat * sc_stride + SC_SW], nullptr, 0, threadIdx.x);
   } else {
     const b3_s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int w = threadIdx.x; w < 16 * 3 * 128; w += NTHREADS) {          // (k8, plane, column) -> 16 zero bytes
-      const int k8 = w / 384, r = w % 384;
-      *reinterpret_cast<b3_s16x8 *>(P + ((int64_t)k8 * 3 * GMAX * NB + (int64_t)(r / 128) * GMAX * NB + (r % 128)) * 8) = z;
+    constexpr int PER = S::NPL * 128;
+    for (int w = threadIdx.x; w < 16 * PER; w += NTHREADS) {              // (k8, plane, column) -> 16 zero bytes
+      const int k8 = w / PER, r = w % PER;
+      *reinterpret_cast<b3_s16x8 *>(P + ((int64_t)k8 * S::NPL * GMAX * NB + (int64_t)(r / 128) * GMAX * NB + (r % 128)) * 8) = z;
     }
   }
 }
 
 // PLMC_BF16X3 (fp32): rows of the factor buffer as planes of `Praw` -- the raw (not yet solved) rows of the FIRST group, which
 // no update kernel has written (every later group's raw rows come out of k_update_bf3).  grid (tiles of the column map, G, q).
+template <class S>
 __global__ __launch_bounds__(NTHREADS) void k_raw_planes(const float *__restrict__ A, int64_t lda, int64_t strideA, int g0, ColMap<float> cm,
-                                                         unsigned short *__restrict__ Praw, int64_t praw_lat_stride, int64_t wcol0) {
+                                                         unsigned short *__restrict__ Praw, int64_t praw_lat_stride, int64_t wcol0,
+                                                         const float *__restrict__ sc, int64_t sc_stride) {
   const int lat = blockIdx.z, t = blockIdx.x, i = blockIdx.y;
-  const float *S;
+  const float *Src;
   int64_t lds_ = lda, colp;
-  if (t < cm.nU) { colp = (int64_t)(cm.u0 + t) * NB; S = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + colp; }
-  else if (t < cm.nU + cm.Taug) { colp = cm.n_pad + (int64_t)(t - cm.nU) * NB; S = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + colp; }
+  if (t < cm.nU) { colp = (int64_t)(cm.u0 + t) * NB; Src = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + colp; }
+  else if (t < cm.nU + cm.Taug) { colp = cm.n_pad + (int64_t)(t - cm.nU) * NB; Src = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + colp; }
   else {
     lds_ = cm.ldw;
     colp = wcol0 + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
-    S = cm.W + (int64_t)lat * cm.strideW + (int64_t)(g0 + i) * NB * lds_ + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
+    Src = cm.W + (int64_t)lat * cm.strideW + (int64_t)(g0 + i) * NB * lds_ + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
   }
-  b3_split_block<false>(S, lds_, Praw + (int64_t)lat * praw_lat_stride + b3_index((int64_t)i * NB, 0, colp, lda), lda, nullptr, 0, threadIdx.x);
+  const float scale = sc[(int64_t)lat * sc_stride + (t < cm.nU + cm.Taug ? SC_RU : SC_RW)];
+  b3_split_block<S, false>(Src, lds_, Praw + (int64_t)lat * praw_lat_stride + b3_index<S>((int64_t)i * NB, 0, colp, lda), lda, scale, nullptr, 0,
+                           threadIdx.x);
 }
 
 // PLMC_BF16X3 (fp32): the group panel on the bf16 matrix cores.  P[i] = sum_{k <= i} Vgg[k][i]^T A[k] for the block rows
@@ -373,12 +431,17 @@ __global__ __launch_bounds__(NTHREADS) void k_raw_planes(const float *__restrict
 // the second (the block Vgg[2 a + 1][2 a] is zero in VgP), heavy and light macro rows paired: y and nm - 1 - y.
 // Accuracy: the product with the inverse triangle cancels; tools/split_numerics_probe.hip holds that case (0.37 x the error
 // of the fp32 MFMA chain).  grid (tiles, (nm + 1) / 2, q), nm = (G + 1) / 2.
+template <class S>
 __global__ __launch_bounds__(B3_NT, 2) void k_gpanel_bf3(float *A, int64_t lda, int64_t strideA, int g0, int G, ColMap<float> cm,
                                                          const unsigned short *__restrict__ VgP, int64_t vgp_lat_stride,
                                                          const unsigned short *__restrict__ Praw, int64_t praw_lat_stride,
-                                                         unsigned short *__restrict__ Pl, int64_t pl_lat_stride, int64_t wcol0) {
-  __shared__ __align__(16) unsigned char lds[B3_LDS_BYTES];
+                                                         unsigned short *__restrict__ Pl, int64_t pl_lat_stride, int64_t wcol0,
+                                                         const float *__restrict__ sc, int64_t sc_stride) {
+  __shared__ __align__(16) unsigned char lds[b3_lds_bytes<S>()];
   const int lat = blockIdx.z, t = blockIdx.x, y = blockIdx.y;
+  const float *scl = sc + (int64_t)lat * sc_stride;
+  const bool wfam = t >= cm.nU + cm.Taug;                              // W columns: raw scale RW, solved scale SW
+  const float unscale = 1.0f / (scl[SC_SW] * scl[wfam ? SC_RW : SC_RU]), pscale = scl[wfam ? SC_SW : SC_SU];
   float *D;
   int64_t ldd = lda, colp;
   if (t < cm.nU) { colp = (int64_t)(cm.u0 + t) * NB; D = A + (int64_t)lat * strideA + (int64_t)g0 * NB * lda + colp; }
@@ -400,14 +463,11 @@ __global__ __launch_bounds__(B3_NT, 2) void k_gpanel_bf3(float *A, int64_t lda, 
     Acc<float> acc0, acc1;
     acc0.zero();
     acc1.zero();
-    b3_mainloop(acc0, acc1, Vp + (int64_t)i0 * NB * 8, (int64_t)GMAX * NB, Rp, lda, (i0 + rows) * NB, lds);
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) acc0.v[u][v] += acc1.v[u][v];
+    b3_mainloop<S>(acc0, acc1, Vp + (int64_t)i0 * NB * 8, (int64_t)GMAX * NB, Rp, lda, (i0 + rows) * NB, lds);
+    b3_combine<S>(acc0, acc1, unscale);
     const int i = i0 + half;
-    b3_writeback<WB_STORE, true>(acc0, D + (int64_t)i * NB * ldd, ldd, reinterpret_cast<float *>(lds + half * B3_WB_BYTES), tid, half < rows,
-                                 Pp + (int64_t)i * 16 * 3 * lda * 8, lda);
+    b3_writeback<S, WB_STORE, true>(acc0, D + (int64_t)i * NB * ldd, ldd, reinterpret_cast<float *>(lds + half * B3_WB_BYTES), tid, half < rows,
+                                    Pp + (int64_t)i * 16 * S::NPL * lda * 8, lda, true, pscale);
     __syncthreads();                     // staging areas free before the next product's DMA lands
   }
 }
@@ -549,9 +609,14 @@ __global__ __launch_bounds__(WTMV_NT) void k_w_diag(const T *__restrict__ W, int
 }
 
 // ----------------------------------------------------------------------------------------------
-template <typename T>
+// S: split scheme of the bulk fp32 products (bf3_engine.hpp); void = none (fp64, or PLMC_SPLIT=0: MFMA of the element type
+// everywhere).  eig_lo: q lower bounds of the smallest eigenvalue (device), needed by SplitH2 only.
+template <typename T, class S>
 int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *Vd, double *logdet, int *info,
-               int with_inverse, int q, void *stream) {
+               int with_inverse, int q, const float *eig_lo, void *stream) {
+  constexpr bool bf3 = !std::is_void<S>::value;
+  using SS = typename std::conditional<bf3, S, SplitB3>::type;       // a valid scheme type for the (dead) template arguments when bf3 is off
+  constexpr bool aug_fp32 = bf3 && SS::NPL == 2;                       // SplitH2 has no a-priori bound for the augmented columns: fp32 engine
   PLMC_REQUIRE(A && Vd && logdet && info, "null pointer");
   PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0 && lda % NB == 0 && lda >= n_pad, "n_pad/lda must be multiples of NB");
   const int64_t naug_pad = plmc_pad(naug);
@@ -571,13 +636,17 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   T *const Ph = Wg + 3 * (int64_t)GMAX * NB * LDG;                      // panel buffer of the head columns (ld LDG)
   T *const Pbulk = Ph + (int64_t)GMAX * NB * LDG;                       // panel buffer of the other columns (ld lda)
   T *const Kd = Vd + strideV - (int64_t)m * NB * NB;                    // diagonal tiles of the accumulated K^-1: last m blocks
-  // PLMC_BF16X3 (fp32, opt-in): rolling two-group buffer of the panel rows as three bf16 planes, behind the bulk panel buffer
-  const bool bf3 = sizeof(T) == 4 && knobs().bf16x3;
-  const int64_t pl_buf = b3_elems((int64_t)GMAX * NB, lda);             // 16-bit elements of one group's planes (k8 order)
+  // split engine (fp32): plane buffers behind the bulk panel buffer -- the rolling two-group buffer of the solved panel rows,
+  // the raw rows of the next group, Vgg, and the scales of the operand families.  The offsets are those of the three-plane
+  // scheme whatever the scheme (plmc_vd_blocks_for sizes the scratch for it).
+  static_assert(!bf3 || sizeof(T) == 4, "split schemes stand in for fp32 products");
+  const int64_t pl_buf = b3_elems<SplitB3>((int64_t)GMAX * NB, lda);    // 16-bit elements reserved per group of rows
   unsigned short *const Pl0 = bf3 ? reinterpret_cast<unsigned short *>(Pbulk + (int64_t)GMAX * NB * lda) : nullptr;
   unsigned short *const Praw = bf3 ? Pl0 + 2 * pl_buf : nullptr;         // raw rows of the group whose panel comes next (one group)
-  unsigned short *const VgP = bf3 ? Praw + pl_buf : nullptr;             // planes of Vgg: b3_elems(128 GMAX, 128 GMAX)
+  unsigned short *const VgP = bf3 ? Praw + pl_buf : nullptr;             // planes of Vgg: 128 GMAX x 128 GMAX
+  float *const scl = bf3 ? reinterpret_cast<float *>(VgP + b3_elems<SplitB3>((int64_t)GMAX * NB, (int64_t)GMAX * NB)) : nullptr;   // SC_N floats
   const int64_t pl_lat = strideV * (int64_t)(sizeof(T) / 2);            // latent stride in 16-bit elements
+  const int64_t sc_lat = strideV * (int64_t)sizeof(T) / 4;              // ... in floats
   const int grp_rows = (knobs().grp > 0 && knobs().grp < GMAX) ? knobs().grp : GMAX;   // block rows per group (as below)
   auto planes = [&](int g0) -> unsigned short * {                       // buffer of the group that starts at block row g0
     return bf3 ? Pl0 + (int64_t)((g0 / grp_rows) & 1) * pl_buf : nullptr;
@@ -650,61 +719,80 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     const double bytes = (2.0 * (tilesU + nr * (cm.Taug + cm.nW)) - nr * nfirst) * nb * nb * esz;
     ProfScope ps(cls, s, q * flops, q * bytes);
     // launches with few tiles run on 64-row half tiles: twice the workgroups
-    // PLMC_BF16X3: which engine a tile goes through must not depend on the schedule (bit-identical results with and
-    // without the look-ahead): every tail / head tile takes the bf16x3 engine on full tiles, the next group's triangle
-    // (U1; `crit`) and the chain stay on the fp32 MFMAs
+    // Split engine: which engine a tile goes through must not depend on the schedule (bit-identical results with and
+    // without the look-ahead): every tail / head tile takes the split engine on macro tiles, the next group's triangle
+    // (U1; `crit`) and the chain stay on the fp32 MFMAs -- and so do the augmented columns under SplitH2 (aug_fp32)
     const bool use_bf3 = bf3 && (cls == PK_TRAIL || (cls == PK_TRAIL_HEAD && !crit));
-    const bool half = !use_bf3 && cls != PK_TRAIL && (double)Cn * nrows * q <= hthr;
-    const dim3 grid(Cn, half ? 2 * nrows : nrows, q);
     const unsigned dyn = (cls == PK_TRAIL || (cls == PK_TRAIL_HEAD && !crit)) ? bulk_lds : 0u;
-    if constexpr (sizeof(T) == 4) {
+    auto fp32_launch = [&](const ColMap<T> &c) {
+      const int cn = c.nU + c.Taug + c.nW;
+      if (cn == 0) return;
+      const bool half = !use_bf3 && cls != PK_TRAIL && (double)cn * nrows * q <= hthr;
+      const dim3 grid(cn, half ? 2 * nrows : nrows, q);
+#define PLMC_UPD(ROLE, MT) \
+  hipLaunchKernelGGL((k_update<T, ROLE, MT>), grid, dim3(NTHREADS), dyn, s, A, lda, strideA, ib0, r_lo, r_hi, c, skip_ib, skip_jb)
+      if (cls == PK_TRAIL_ROW) { if (half && q <= 2 && r_hi == r_lo) PLMC_UPD(4, 2); else if (half) PLMC_UPD(1, 2); else PLMC_UPD(1, 4); }
+      else if (cls == PK_TRAIL_HEAD && crit) { if (half) PLMC_UPD(2, 2); else PLMC_UPD(2, 4); }
+      else if (cls == PK_TRAIL_HEAD) { if (half) PLMC_UPD(3, 2); else PLMC_UPD(3, 4); }
+      else PLMC_UPD(0, 4);
+#undef PLMC_UPD
+    };
+    if constexpr (bf3) {
       if (use_bf3) {
+        ColMap<T> cb = cm, ca = cm;
+        if (aug_fp32) { cb.Taug = 0; ca.nU = 0; ca.nW = 0; }
+        const int cnb = cb.nU + cb.Taug + cb.nW;
         const unsigned short *pl = planes(r_lo);
-        const dim3 gridb(Cn, (nrows + 1) / 2, q);
-        if (cls == PK_TRAIL)
-          hipLaunchKernelGGL((k_update_bf3<0>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cm, skip_ib, skip_jb, pl, pl_lat, wcol0,
-                             Praw, pl_lat, raw_end);
-        else
-          hipLaunchKernelGGL((k_update_bf3<3>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cm, skip_ib, skip_jb, pl, pl_lat, wcol0,
-                             Praw, pl_lat, raw_end);
+        const dim3 gridb(cnb, (nrows + 1) / 2, q);
+        if (cnb > 0) {
+          if (cls == PK_TRAIL)
+            hipLaunchKernelGGL((k_update_bf3<SS, 0>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cb, skip_ib, skip_jb, pl, pl_lat,
+                               wcol0, Praw, pl_lat, raw_end, (const float *)scl, sc_lat);
+          else
+            hipLaunchKernelGGL((k_update_bf3<SS, 3>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cb, skip_ib, skip_jb, pl, pl_lat,
+                               wcol0, Praw, pl_lat, raw_end, (const float *)scl, sc_lat);
+        }
+        if (aug_fp32) fp32_launch(ca);
         return;
       }
     }
-#define PLMC_UPD(ROLE, MT) \
-  hipLaunchKernelGGL((k_update<T, ROLE, MT>), grid, dim3(NTHREADS), dyn, s, A, lda, strideA, ib0, r_lo, r_hi, cm, skip_ib, skip_jb)
-    if (cls == PK_TRAIL_ROW) { if (half && q <= 2 && r_hi == r_lo) PLMC_UPD(4, 2); else if (half) PLMC_UPD(1, 2); else PLMC_UPD(1, 4); }
-    else if (cls == PK_TRAIL_HEAD && crit) { if (half) PLMC_UPD(2, 2); else PLMC_UPD(2, 4); }
-    else if (cls == PK_TRAIL_HEAD) { if (half) PLMC_UPD(3, 2); else PLMC_UPD(3, 4); }
-    else PLMC_UPD(0, 4);
-#undef PLMC_UPD
+    fp32_launch(cm);
   };
   // head != 0: the few columns of the next group (panel buffer Ph), on the chain stream
   auto gpanel = [&](int g0, int G, const ColMap<T> &cm, const T *Vg, hipStream_t s, int head) {
     const int nt = cm.nU + cm.Taug + cm.nW;
     if (nt == 0) return;
     const double prods = G * (G + 1) / 2.0;               // 128-deep tile products per column strip
-    if constexpr (sizeof(T) == 4) {
-      if (bf3 && !head) {                                  // bf16 engine, in place, planes from the epilogue (k_gpanel_bf3)
-        ProfScope ps(PK_GPANEL, s, q * (double)nt * prods * 2.0 * nb3, q * (double)nt * (prods + G) * nb * nb * esz);
-        const int nm = (G + 1) / 2;
-        hipLaunchKernelGGL(k_gpanel_bf3, dim3(nt, (nm + 1) / 2, q), dim3(B3_NT), 0, s, A, lda, strideA, g0, G, cm, (const unsigned short *)VgP, pl_lat,
-                           (const unsigned short *)Praw, pl_lat, planes(g0), pl_lat, wcol0);
+    ProfScope ps(PK_GPANEL, s, q * (double)nt * prods * 2.0 * nb3, q * (double)nt * (prods + G) * nb * nb * esz);
+    // fp32 engine: out of place into a panel buffer + copy (the copy also writes the planes of the solved rows when the
+    // split engine is on: the head columns R1 feed the tail / head updates as operands)
+    auto fp32_panel = [&](const ColMap<T> &c, bool with_planes) {
+      const int ct = c.nU + c.Taug + c.nW;
+      if (ct == 0) return;
+      T *Pb = head ? Ph : Pbulk;
+      const int64_t ldp = head ? (int64_t)LDG : lda;
+      if (head)
+        hipLaunchKernelGGL((k_gpanel_rows<T, 1>), dim3(ct, 2 * G, q), dim3(NTHREADS), 0, s, (const T *)A, lda, strideA, g0, G, c, Vg, (int64_t)LDG,
+                           strideV, Pb, ldp, strideV);
+      else
+        hipLaunchKernelGGL((k_gpanel_rows<T, 0>), dim3(ct, (G + 1) / 2, q), dim3(NTHREADS), bulk_lds, s, (const T *)A, lda, strideA, g0, G, c, Vg,
+                           (int64_t)LDG, strideV, Pb, ldp, strideV);
+      hipLaunchKernelGGL((k_gpanel_copy<T, SS>), dim3(ct, G, q), dim3(NTHREADS), 0, s, A, lda, strideA, g0, c, (const T *)Pb, ldp, strideV,
+                         with_planes ? planes(g0) : (unsigned short *)nullptr, pl_lat, wcol0, (const float *)scl, sc_lat);
+    };
+    if constexpr (bf3) {
+      if (!head) {                                         // split engine, in place, planes from the epilogue (k_gpanel_bf3)
+        ColMap<T> cb = cm, ca = cm;
+        if (aug_fp32) { cb.Taug = 0; ca.nU = 0; ca.nW = 0; }
+        const int nb_ = cb.nU + cb.Taug + cb.nW, nm = (G + 1) / 2;
+        if (nb_ > 0)
+          hipLaunchKernelGGL((k_gpanel_bf3<SS>), dim3(nb_, (nm + 1) / 2, q), dim3(B3_NT), 0, s, A, lda, strideA, g0, G, cb, (const unsigned short *)VgP,
+                             pl_lat, (const unsigned short *)Praw, pl_lat, planes(g0), pl_lat, wcol0, (const float *)scl, sc_lat);
+        if (aug_fp32) fp32_panel(ca, false);
         return;
       }
     }
-    T *Pb = head ? Ph : Pbulk;
-    const int64_t ldp = head ? (int64_t)LDG : lda;
-    {
-      ProfScope ps(PK_GPANEL, s, q * (double)nt * prods * 2.0 * nb3, q * (double)nt * (prods + G) * nb * nb * esz);
-      if (head)
-        hipLaunchKernelGGL((k_gpanel_rows<T, 1>), dim3(nt, 2 * G, q), dim3(NTHREADS), 0, s, (const T *)A, lda, strideA, g0, G, cm, Vg, (int64_t)LDG,
-                           strideV, Pb, ldp, strideV);
-      else
-        hipLaunchKernelGGL((k_gpanel_rows<T, 0>), dim3(nt, (G + 1) / 2, q), dim3(NTHREADS), bulk_lds, s, (const T *)A, lda, strideA, g0, G, cm, Vg,
-                           (int64_t)LDG, strideV, Pb, ldp, strideV);
-    }
-    hipLaunchKernelGGL((k_gpanel_copy<T>), dim3(nt, G, q), dim3(NTHREADS), 0, s, A, lda, strideA, g0, cm, (const T *)Pb, ldp, strideV,
-                       planes(g0), pl_lat, wcol0);
+    fp32_panel(cm, bf3);
   };
 
   // whole-sweep bracket on the caller's stream (the per-kernel records of overlapped kernels add up to
@@ -714,6 +802,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // tiles of the diagonal-block outputs that k_diag leaves alone (they are read as parts of full 128 x 128 operands)
   hipLaunchKernelGGL(k_zero_diag_out<T>, dim3(m > GMAX ? m : GMAX, q), dim3(NTHREADS), 0, st, Vd, strideV, m, Wg, (int64_t)LDG,
                      strideV, (int64_t)NB * LDG + NB, GMAX);
+  if constexpr (bf3)                                      // scales of the operand families (SplitB3: ones), before anything splits
+    hipLaunchKernelGGL((k_split_scales<SS>), dim3(q), dim3(NTHREADS), 0, st, (const float *)A, n_pad, lda, strideA, eig_lo, scl, sc_lat);
   auto finish = [&]() {
     hipLaunchKernelGGL(k_logdet<T>, dim3(q), dim3(NTHREADS), 0, st, (const T *)A, n_pad, lda, strideA, logdet, info);
     return launch_status("potrf_impl");
@@ -762,27 +852,28 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   };
   // PLMC_BF16X3: planes of the group's inverse triangle (read back from the W columns k_vtrans wrote; any stream behind it)
   auto wtri_planes = [&](int gi, hipStream_t s) {
-    if constexpr (sizeof(T) == 4) {
-      if (!bf3 || !WA) return;
+    if constexpr (bf3) {
+      if (!WA) return;
       const int g0 = G0(gi), G = G0(gi + 1) - g0;
-      hipLaunchKernelGGL(k_wtri_planes, dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const float *)WA, lda, strideA, g0, planes(g0), pl_lat, wcol0);
+      hipLaunchKernelGGL((k_wtri_planes<SS>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const float *)WA, lda, strideA, g0, planes(g0), pl_lat,
+                         wcol0, (const float *)scl, sc_lat);
     }
   };
   // PLMC_BF16X3: planes of Vgg for the group panel (behind k_vtrans; same stream as the panel that reads them)
   auto vg_planes = [&](int gi, hipStream_t s) {
-    if constexpr (sizeof(T) == 4) {
-      if (!bf3) return;
-      hipLaunchKernelGGL(k_vg_planes, dim3(GMAX * GMAX, q), dim3(NTHREADS), 0, s, (const float *)Vg2[gi & 1], strideV, G0(gi + 1) - G0(gi), VgP, pl_lat);
-    }
+    if constexpr (bf3)
+      hipLaunchKernelGGL((k_vg_planes<SS>), dim3(GMAX * GMAX, q), dim3(NTHREADS), 0, s, (const float *)Vg2[gi & 1], strideV, G0(gi + 1) - G0(gi), VgP,
+                         pl_lat, (const float *)scl, sc_lat);
   };
   // PLMC_BF16X3: planes of the first group's raw rows (columns of the bulk panel: everything right of the second group + aug)
   auto raw_planes0 = [&](hipStream_t s, int u0) {
-    if constexpr (sizeof(T) == 4) {
-      if (!bf3) return;
+    if constexpr (bf3) {
       const int g1 = G0(1);
-      const ColMap<float> cm = cm_buf(u0, m - u0, Taug, 0, 0);
+      const ColMap<float> cm = cm_buf(u0, m - u0, aug_fp32 ? 0 : Taug, 0, 0);
       const int nt = cm.nU + cm.Taug + cm.nW;
-      if (nt > 0) hipLaunchKernelGGL(k_raw_planes, dim3(nt, g1, q), dim3(NTHREADS), 0, s, (const float *)A, lda, strideA, 0, cm, Praw, pl_lat, wcol0);
+      if (nt > 0)
+        hipLaunchKernelGGL((k_raw_planes<SS>), dim3(nt, g1, q), dim3(NTHREADS), 0, s, (const float *)A, lda, strideA, 0, cm, Praw, pl_lat, wcol0,
+                           (const float *)scl, sc_lat);
     }
   };
 
@@ -928,17 +1019,37 @@ int64_t plmc_vd_blocks_for(int64_t n_pad, int64_t lda, int elem_bytes) {
   const int64_t ldb = (lda + plmc::NB - 1) / plmc::NB;
   // planes (4-byte elements): rolling buffer of the solved panel rows (2 groups) + raw rows of the next group (1 group), each
   // 128 GMAX rows x 3 planes x lda x 2 bytes = 12 ldb blocks at GMAX = 8, + Vgg (3 x (128 GMAX)^2 x 2 bytes = 96 blocks)
-  const int64_t planes = elem_bytes == 4 ? 3 * (3 * plmc::GMAX * ldb / 2) + 6 * plmc::GMAX * plmc::GMAX / 4 : 0;
+  // + 1 block holding the scales of the operand families
+  const int64_t planes = elem_bytes == 4 ? 3 * (3 * plmc::GMAX * ldb / 2) + 6 * plmc::GMAX * plmc::GMAX / 4 + 1 : 0;
   return 2 * (n_pad / plmc::NB) + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ldb + planes;
 }
 int64_t plmc_vd_blocks(int64_t n_pad, int64_t lda) { return plmc_vd_blocks_for(n_pad, lda, 4); }
+// PLMC_SPLIT picks the arithmetic of the bulk fp32 products: 0 = fp32 MFMA everywhere, 3 = SplitB3, 2 (default) = SplitH2
+// where the caller supplies eigenvalue bounds (plmc_potrf_ex_f32), SplitB3 otherwise.
+static int potrf_f32_any(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet, int *info,
+                         int with_inverse, int q, const float *eig_lo, void *stream) {
+  const int split = plmc::knobs().split;
+  if (split == 0) return plmc::potrf_impl<float, void>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, nullptr, stream);
+  if (split == 2 && eig_lo)
+    return plmc::potrf_impl<float, plmc::SplitH2>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, eig_lo, stream);
+  return plmc::potrf_impl<float, plmc::SplitB3>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, nullptr, stream);
+}
 int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet,
                    int *info, int with_inverse, int q, void *stream) {
-  return plmc::potrf_impl<float>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, stream);
+  return potrf_f32_any(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, nullptr, stream);
 }
 int plmc_potrf_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, double *Vd, double *logdet,
                    int *info, int with_inverse, int q, void *stream) {
-  return plmc::potrf_impl<double>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, stream);
+  return plmc::potrf_impl<double, void>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, nullptr, stream);
+}
+int plmc_potrf_ex_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet,
+                      int *info, int with_inverse, int q, const float *eig_lo, void *stream) {
+  return potrf_f32_any(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, eig_lo, stream);
+}
+int plmc_potrf_ex_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, double *Vd, double *logdet,
+                      int *info, int with_inverse, int q, const double *eig_lo, void *stream) {
+  (void)eig_lo;
+  return plmc::potrf_impl<double, void>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, nullptr, stream);
 }
 int plmc_extract_col_f32(const float *A, int64_t n_pad, int64_t lda, int64_t strideA, int c, float *z, double *quad,
                          int q, void *stream) {

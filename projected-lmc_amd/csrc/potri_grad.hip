@@ -133,7 +133,10 @@ __device__ __forceinline__ void kinv_tile_epilogue(const Acc<T> &acc, T *smem, c
                                                    const T *__restrict__ ell, const T *__restrict__ oscale, T *Kinv, int64_t ldk,
                                                    int64_t strideK, T *kinv_diag, double *__restrict__ partials, int plain) {
   if (!live) { n = 0; Kinv = nullptr; kinv_diag = nullptr; }       // every element predicate below is then false
+  // 512 threads = two waves per SIMD = 256 registers: with 32 dimensions the one-pass form does not fit beside the accumulators
+#define PLMC_KINV_KEEP (DCAP <= 16)
 #include "kinv_epilogue.inc"
+#undef PLMC_KINV_KEEP
 }
 
 // SPLINE (general epilogue only): the product-form spline kernel gets its own instantiation, so that its extra live
@@ -168,7 +171,9 @@ __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad
   // sits at exactly 128 registers, 24 bytes of scratch per lane
   const int tid = threadIdx.x;
   constexpr bool live = true;
+#define PLMC_KINV_KEEP (sizeof(T) == 4)
 #include "kinv_epilogue.inc"
+#undef PLMC_KINV_KEEP
 }
 
 // The same on the bf16 matrix cores (fp32 only; bf3_engine.hpp): a workgroup of 512 threads takes the macro tile
@@ -177,13 +182,14 @@ __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad
 // Order: longest K range first (jb ascending), latent fastest; macro tiles of column jb: ib = 0, 2, .. <= jb.
 // number of macro tiles in block columns < j:  j even: (j/2)^2 + j/2,  j odd: ((j+1)/2)^2
 __host__ __device__ inline int kinv_macro_before(int j) { const int a = j >> 1; return (j & 1) ? (a + 1) * (a + 1) : a * a + a; }
-template <int DCAP, bool SPLINE = false>
+// `wscale`: per latent the power-of-two scale the planes of W were written with (SplitH2; SplitB3: ones).
+template <class S, int DCAP, bool SPLINE = false>
 __global__ __launch_bounds__(B3_NT, 2) void k_kinv_grad_bf3(int kind, int64_t n_pad, const float *__restrict__ alpha, const float *__restrict__ X, int n,
                                                             int d, const float *__restrict__ ell, const float *__restrict__ oscale, float *Kinv,
                                                             int64_t ldk, int64_t strideK, float *kinv_diag, double *__restrict__ partials, int nlat,
-                                                            int plain, const unsigned short *__restrict__ Wp) {
-  __shared__ __align__(16) unsigned char lds[B3_LDS_BYTES];
-  static_assert(2 * tile_smem_elems<float>() * sizeof(float) <= B3_LDS_BYTES, "two epilogue staging areas");
+                                                            int plain, const unsigned short *__restrict__ Wp, const float *__restrict__ wscale) {
+  constexpr int LDS_BYTES = b3_lds_bytes<S>() > 2 * tile_smem_elems<float>() * (int)sizeof(float) ? b3_lds_bytes<S>() : 2 * tile_smem_elems<float>() * (int)sizeof(float);
+  __shared__ __align__(16) unsigned char lds[LDS_BYTES];
   const int m = (int)(n_pad / NB);
   const int w = blockIdx.x, lat = w % nlat, t = w / nlat;
   int jb = (int)(2.0f * sqrtf((float)t));
@@ -194,12 +200,10 @@ __global__ __launch_bounds__(B3_NT, 2) void k_kinv_grad_bf3(int kind, int64_t n_
   Acc<float> acc0, acc1;
   acc0.zero();
   acc1.zero();
-  const unsigned short *Pl = Wp + (int64_t)lat * b3_elems(n_pad, n_pad) + b3_index((int64_t)jb * NB, 0, 0, n_pad);
-  b3_mainloop(acc0, acc1, Pl + (int64_t)ibm * NB * 8, n_pad, Pl + (int64_t)jb * NB * 8, n_pad, (int)(n_pad - (int64_t)jb * NB), lds);
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc0.v[a][b] += acc1.v[a][b];
+  const unsigned short *Pl = Wp + (int64_t)lat * b3_elems<S>(n_pad, n_pad) + b3_index<S>((int64_t)jb * NB, 0, 0, n_pad);
+  b3_mainloop<S>(acc0, acc1, Pl + (int64_t)ibm * NB * 8, n_pad, Pl + (int64_t)jb * NB * 8, n_pad, (int)(n_pad - (int64_t)jb * NB), lds);
+  const float ws = wscale[lat];
+  b3_combine<S>(acc0, acc1, 1.0f / (ws * ws));
   const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
   const int ib = ibm + half;
   kinv_tile_epilogue<float, DCAP, SPLINE>(acc0, reinterpret_cast<float *>(lds) + half * tile_smem_elems<float>(), (int)threadIdx.x & 255, ib <= jb, kind,
@@ -370,22 +374,38 @@ int grad_tiles_impl(int kind, const T *A, int64_t n_pad, int64_t lda, int64_t st
   return launch_status(__func__);
 }
 
-// Three-plane bf16 split of the inverse factor for the bf16-engine gradient kernel: W (fp32, lower block triangle: block
-// (lb, cb) with cb <= lb) -> k8-ordered planes Wp[latent][k / 8][plane][n_pad columns][k % 8] (bf3_engine.hpp).
-// grid (m, m, q), one 128 x 128 block per workgroup; HBM-bound (4 bytes read, 6 written per element).
+// Split of the inverse factor for the split-engine gradient kernel: W (fp32, lower block triangle: block (lb, cb) with
+// cb <= lb) -> k8-ordered planes Wp[latent][k / 8][plane][n_pad columns][k % 8] (bf3_engine.hpp), every value times the
+// latent's scale `wscale` (SplitH2: 2^13 / bound of |W|, written by k_w_scale; SplitB3: 1).
+// grid (m, m, q), one 128 x 128 block per workgroup; HBM-bound (4 bytes read, 2 NPL written per element).
+template <class S>
 __global__ __launch_bounds__(NTHREADS) void k_split_w(const float *__restrict__ W, int64_t n_pad, int64_t ldw, int64_t strideW,
-                                                      unsigned short *__restrict__ Wp) {
+                                                      unsigned short *__restrict__ Wp, const float *__restrict__ wscale) {
   const int cb = blockIdx.x, lb = blockIdx.y, lat = blockIdx.z;
   if (cb > lb) return;
-  b3_split_block<false>(W + (int64_t)lat * strideW + (int64_t)lb * NB * ldw + (int64_t)cb * NB, ldw,
-                        Wp + (int64_t)lat * b3_elems(n_pad, n_pad) + b3_index((int64_t)lb * NB, 0, (int64_t)cb * NB, n_pad), n_pad, nullptr, 0,
-                        threadIdx.x);
+  b3_split_block<S, false>(W + (int64_t)lat * strideW + (int64_t)lb * NB * ldw + (int64_t)cb * NB, ldw,
+                           Wp + (int64_t)lat * b3_elems<S>(n_pad, n_pad) + b3_index<S>((int64_t)lb * NB, 0, (int64_t)cb * NB, n_pad), n_pad, wscale[lat],
+                           nullptr, 0, threadIdx.x);
+}
+// wscale[lat] = scale for |W_ij| <= 1 / sqrt(lambda_min(Khat)) <= 1 / sqrt(eig_lo[lat])  (SplitB3 / no bound: 1); the identity
+// padding of the rows beyond n has eigenvalue 1 whatever the noise (`padded`).  1 x q threads.
+template <class S>
+__global__ void k_w_scale(const float *__restrict__ eig_lo, float *__restrict__ wscale, int q, int padded) {
+  const int lat = threadIdx.x;
+  if (lat >= q) return;
+  if constexpr (S::NPL == 3) wscale[lat] = 1.0f;
+  else {
+    float lam = fmaxf(eig_lo[lat], 1e-30f);
+    if (padded) lam = fminf(lam, 1.0f);
+    wscale[lat] = b3_scale_for(1.0f / sqrtf(lam));
+  }
 }
 
-template <typename T>
+// S: split scheme of the W^T W products (void: MFMA of the element type); eig_lo: see potrf_impl.
+template <typename T, class S>
 int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, const T *alpha, const T *X, int n,
                    int d, const T *ell, const T *oscale, double *grad, T *Kinv, int64_t ldk, int64_t strideK,
-                   T *kinv_diag, void *partials, int q, void *stream) {
+                   T *kinv_diag, void *partials, int q, const float *eig_lo, void *stream) {
   PLMC_REQUIRE(kind >= 0 && kind <= 4, "unknown kernel kind");
   PLMC_REQUIRE(W && alpha && X && ell && grad && partials, "null pointer");
   PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0 && ldw % NB == 0 && n <= n_pad && n > n_pad - NB, "n_pad must be plmc_pad(n)");
@@ -403,28 +423,30 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
   const dim3 grid = plain >= 4 ? dim3(q * (m * (m + 1) / 2)) : plain ? dim3(m, m, q) : dim3(xcd_tri_grid(m, q)), block(NTHREADS);
   double *part = reinterpret_cast<double *>(partials);
   const double np = (double)n_pad;
-  // fp32 products on the bf16 matrix cores (PLMC_BF16X3, the fp32 default; bf3_engine.hpp): split W into k8-ordered bf16
-  // planes behind the partials, then the macro-tile kernel
+  // split engine (bf3_engine.hpp): split W into k8-ordered planes behind the partials (and the q scales behind the
+  // planes), then the macro-tile kernel
   bool done = false;
-  if constexpr (sizeof(T) == 4) {
-    if (knobs().bf16x3) {
-      unsigned short *wp = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(partials) + (int64_t)m * m * q * GP * (int64_t)sizeof(double));
-      {
-        ProfScope ps(PK_SPLIT, st, 0.0, (double)q * np * np / 2 * (4 + 6));
-        hipLaunchKernelGGL(k_split_w, dim3(m, m, q), dim3(NTHREADS), 0, st, (const float *)W, n_pad, ldw, strideW, wp);
-      }
-      const dim3 gridb(q * kinv_macro_before(m));
-#define PLMC_LAUNCH_KB(DC, SP) \
-  hipLaunchKernelGGL((k_kinv_grad_bf3<DC, SP>), gridb, dim3(B3_NT), 0, st, kind, n_pad, alpha, X, n, d, ell, oscale, Kinv, ldk, strideK, kinv_diag, \
-                     part, q, plain, (const unsigned short *)wp)
-      ProfScope ps(PK_KINV_GRAD, st, q * np * np * np / 3.0, q * (np * np / 2) * sizeof(T));
-      if (d <= 4) PLMC_LAUNCH_KB(4, false);
-      else if (d <= 8) PLMC_LAUNCH_KB(8, false);
-      else if (d <= 16) { if (kind == K_SPLINE) PLMC_LAUNCH_KB(16, true); else PLMC_LAUNCH_KB(16, false); }
-      else { if (kind == K_SPLINE) PLMC_LAUNCH_KB(32, true); else PLMC_LAUNCH_KB(32, false); }
-#undef PLMC_LAUNCH_KB
-      done = true;
+  if constexpr (!std::is_void<S>::value) {
+    PLMC_REQUIRE(q <= 1024, "too many latents for one scale launch");
+    char *pb = reinterpret_cast<char *>(partials) + (int64_t)m * m * q * GP * (int64_t)sizeof(double);
+    unsigned short *wp = reinterpret_cast<unsigned short *>(pb);
+    float *wsc = reinterpret_cast<float *>(pb + (int64_t)q * b3_elems<SplitB3>(n_pad, n_pad) * 2);
+    hipLaunchKernelGGL((k_w_scale<S>), dim3(1), dim3(q < 64 ? 64 : ((q + 63) / 64) * 64), 0, st, eig_lo, wsc, q, (int)(n < n_pad));
+    {
+      ProfScope ps(PK_SPLIT, st, 0.0, (double)q * np * np / 2 * (4 + 2 * S::NPL));
+      hipLaunchKernelGGL((k_split_w<S>), dim3(m, m, q), dim3(NTHREADS), 0, st, (const float *)W, n_pad, ldw, strideW, wp, (const float *)wsc);
     }
+    const dim3 gridb(q * kinv_macro_before(m));
+#define PLMC_LAUNCH_KB(DC, SP) \
+  hipLaunchKernelGGL((k_kinv_grad_bf3<S, DC, SP>), gridb, dim3(B3_NT), 0, st, kind, n_pad, alpha, X, n, d, ell, oscale, Kinv, ldk, strideK, kinv_diag, \
+                     part, q, plain, (const unsigned short *)wp, (const float *)wsc)
+    ProfScope ps(PK_KINV_GRAD, st, q * np * np * np / 3.0, q * (np * np / 2) * sizeof(T));
+    if (d <= 4) PLMC_LAUNCH_KB(4, false);
+    else if (d <= 8) PLMC_LAUNCH_KB(8, false);
+    else if (d <= 16) { if (kind == K_SPLINE) PLMC_LAUNCH_KB(16, true); else PLMC_LAUNCH_KB(16, false); }
+    else { if (kind == K_SPLINE) PLMC_LAUNCH_KB(32, true); else PLMC_LAUNCH_KB(32, false); }
+#undef PLMC_LAUNCH_KB
+    done = true;
   }
 #define PLMC_LAUNCH_KG(DC, SP)                                                                                       \
   hipLaunchKernelGGL((k_kinv_grad<T, DC, SP>), grid, block, 0, st, kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, \
@@ -460,22 +482,49 @@ int plmc_grad_tiles_f64(int kind, const double *A, int64_t n_pad, int64_t lda, i
 // per-tile partial sums + (4-byte elements) the bf16 planes of W for the bf16 engine; independent of the knobs
 int64_t plmc_grad_scratch_bytes_for(int64_t n_pad, int q, int elem_bytes) {
   int64_t m = n_pad / plmc::NB;
-  const int64_t planes = elem_bytes == 4 ? (int64_t)q * plmc::b3_elems(n_pad, n_pad) * 2 : 0;
+  const int64_t planes = elem_bytes == 4 ? (int64_t)q * plmc::b3_elems<plmc::SplitB3>(n_pad, n_pad) * 2 + 4096 : 0;   // + the q scales
   return m * m * (int64_t)q * plmc::GP * (int64_t)sizeof(double) + planes;
 }
 int64_t plmc_grad_scratch_bytes(int64_t n_pad, int q) { return plmc_grad_scratch_bytes_for(n_pad, q, 4); }
+static int kinv_grad_f32_any(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW, const float *alpha,
+                             const float *X, int n, int d, const float *ell, const float *oscale, double *grad,
+                             float *Kinv, int64_t ldk, int64_t strideK, float *kinv_diag, void *partials, int q, const float *eig_lo,
+                             void *stream) {
+  const int split = plmc::knobs().split;
+  if (split == 0)
+    return plmc::kinv_grad_impl<float, void>(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk, strideK, kinv_diag, partials, q,
+                                             nullptr, stream);
+  if (split == 2 && eig_lo)
+    return plmc::kinv_grad_impl<float, plmc::SplitH2>(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk, strideK, kinv_diag,
+                                                      partials, q, eig_lo, stream);
+  return plmc::kinv_grad_impl<float, plmc::SplitB3>(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk, strideK, kinv_diag,
+                                                    partials, q, nullptr, stream);
+}
 int plmc_kinv_grad_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW, const float *alpha,
                        const float *X, int n, int d, const float *ell, const float *oscale, double *grad,
                        float *Kinv, int64_t ldk, int64_t strideK, float *kinv_diag, void *partials, int q,
                        void *stream) {
-  return plmc::kinv_grad_impl<float>(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk,
-                                     strideK, kinv_diag, partials, q, stream);
+  return kinv_grad_f32_any(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk, strideK, kinv_diag, partials, q, nullptr, stream);
+}
+int plmc_kinv_grad_ex_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW, const float *alpha,
+                          const float *X, int n, int d, const float *ell, const float *oscale, double *grad,
+                          float *Kinv, int64_t ldk, int64_t strideK, float *kinv_diag, void *partials, int q,
+                          const float *eig_lo, void *stream) {
+  return kinv_grad_f32_any(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk, strideK, kinv_diag, partials, q, eig_lo, stream);
 }
 int plmc_kinv_grad_f64(int kind, const double *W, int64_t n_pad, int64_t ldw, int64_t strideW, const double *alpha,
                        const double *X, int n, int d, const double *ell, const double *oscale, double *grad,
                        double *Kinv, int64_t ldk, int64_t strideK, double *kinv_diag, void *partials, int q,
                        void *stream) {
-  return plmc::kinv_grad_impl<double>(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk,
-                                      strideK, kinv_diag, partials, q, stream);
+  return plmc::kinv_grad_impl<double, void>(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk,
+                                            strideK, kinv_diag, partials, q, nullptr, stream);
+}
+int plmc_kinv_grad_ex_f64(int kind, const double *W, int64_t n_pad, int64_t ldw, int64_t strideW, const double *alpha,
+                          const double *X, int n, int d, const double *ell, const double *oscale, double *grad,
+                          double *Kinv, int64_t ldk, int64_t strideK, double *kinv_diag, void *partials, int q,
+                          const double *eig_lo, void *stream) {
+  (void)eig_lo;
+  return plmc::kinv_grad_impl<double, void>(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk,
+                                            strideK, kinv_diag, partials, q, nullptr, stream);
 }
 }

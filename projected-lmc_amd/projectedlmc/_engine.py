@@ -133,8 +133,10 @@ def factorize(kind, X, ell, oscale, noise, rhs, ws, Xs=None, kacc=False):
     if Xs is not None:
         L.call("plmc_assemble_cross", dt, k, _hip.ptr(X), n, _hip.ptr(Xs), Xs.shape[0], d, _hip.ptr(ell),
                _hip.ptr(oscale), _hip.ptr(ws.A), ws.lda, ws.strideA, ws.n_pad + nrhs, ws.n_pad, q, st)
-    L.call("plmc_potrf", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.naug, ws.strideA, _hip.ptr(ws.Vd),
-           _hip.ptr(ws.logdet), _hip.ptr(ws.info), (2 if kacc else 1) if ws.with_inverse else 0, q, st)
+    # eig_lo = the noise variances: lambda_min(K + s2 I) >= s2 -- the bound the two-plane fp16 split of the bulk fp32 products
+    # scales its operands with (include/plmc.h, plmc_potrf_ex_*); ignored by the fp64 entry point
+    L.call("plmc_potrf_ex", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.naug, ws.strideA, _hip.ptr(ws.Vd),
+           _hip.ptr(ws.logdet), _hip.ptr(ws.info), (2 if kacc else 1) if ws.with_inverse else 0, q, _hip.ptr(noise), st)
 
 
 def sweep_accumulates_kinv():
@@ -260,7 +262,7 @@ class ExactLatentLogProb(torch.autograd.Function):
                 if gs is not None:
                     gs.wait_stream(torch.cuda.current_stream(dev))
                     gst = _hip.stream_handle(gs, dev)
-                    for t in (grad, Xc, ellc, osc):
+                    for t in (grad, Xc, ellc, osc, noise_eff):
                         if t is not None:
                             t.record_stream(gs)
                 if kacc:
@@ -268,9 +270,9 @@ class ExactLatentLogProb(torch.autograd.Function):
                            _hip.ptr(ws.alpha), _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad), None,
                            _hip.ptr(ws.partials), q, gst)
                 else:
-                    L.call("plmc_kinv_grad", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW,
+                    L.call("plmc_kinv_grad_ex", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW,
                            _hip.ptr(ws.alpha), _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad),
-                           None, 0, 0, None, _hip.ptr(ws.partials), q, gst)
+                           None, 0, 0, None, _hip.ptr(ws.partials), q, _hip.ptr(noise_eff), gst)
                 if gs is not None:
                     ws.pending = torch.cuda.Event()
                     ws.pending.record(gs)
@@ -406,9 +408,9 @@ def exact_loo(kind, X, ell, oscale, noise, y):
            _hip.ptr(ws.alpha), q, st)
     grad = torch.empty(q, d + 2, dtype=torch.float64, device=dev)
     kd = torch.empty(q, ws.n_pad, dtype=dt, device=dev)
-    L.call("plmc_kinv_grad", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.alpha),
+    L.call("plmc_kinv_grad_ex", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.alpha),
            _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad), None, 0, 0, _hip.ptr(kd),
-           _hip.ptr(ws.partials), q, st)
+           _hip.ptr(ws.partials), q, _hip.ptr(nzc), st)
     sigma2 = 1.0 / kd[:, :n]
     return sigma2, ws.alpha[:, :n] * sigma2
 

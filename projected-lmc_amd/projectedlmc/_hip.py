@@ -27,11 +27,13 @@ _TYPED = {
     "plmc_write_rhs": [_P, _I, _I, _P, _L, _L, _I, _I, _I, _P],
     "plmc_assemble_cross": [_I, _P, _I, _P, _I, _I, _P, _P, _P, _L, _L, _L, _L, _I, _P],
     "plmc_potrf": [_P, _L, _L, _I, _L, _P, _P, _P, _I, _I, _P],
+    "plmc_potrf_ex": [_P, _L, _L, _I, _L, _P, _P, _P, _I, _I, _P, _P],
     "plmc_extract_col": [_P, _L, _L, _L, _I, _P, _P, _I, _P],
     "plmc_wt_matvec": [_P, _L, _L, _L, _P, _P, _I, _P],
     "plmc_w_diag": [_P, _L, _L, _L, _P, _I, _P],
     "plmc_gemm_tn": [_I, _I, _I, _I, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P],
     "plmc_kinv_grad": [_I, _P, _L, _L, _L, _P, _P, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P],
+    "plmc_kinv_grad_ex": [_I, _P, _L, _L, _L, _P, _P, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P, _P],
     "plmc_grad_tiles": [_I, _P, _L, _L, _L, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     "plmc_lmc_assemble": [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P],
     "plmc_lmc_cross": [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _P],

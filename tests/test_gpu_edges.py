@@ -179,22 +179,23 @@ def test_sarcos_scale_single_latent_fp32(eng):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("n,q,dtype,bf3", [(8192, 8, torch.float32, True), (8192, 2, torch.float32, True),
-                                             (4096, 4, torch.float64, True), (8192, 4, torch.float32, False), (8192, 8, torch.float32, False)],
-                         ids=["metric-f32-q8-wsplit", "f32-q2-two-streams", "f64-q4", "f32-q4-fp32-mfma", "metric-f32-q8-fp32-mfma"])
-def test_sweep_is_deterministic_and_schedule_independent(eng, n, q, dtype, bf3):
+@pytest.mark.parametrize("n,q,dtype,split", [(8192, 8, torch.float32, 2), (8192, 2, torch.float32, 2), (4096, 4, torch.float64, 2),
+                                               (8192, 4, torch.float32, 3), (8192, 4, torch.float32, 0), (8192, 8, torch.float32, 0)],
+                         ids=["metric-f32-q8-wsplit", "f32-q2-two-streams", "f64-q4", "f32-q4-bf16x3", "f32-q4-fp32-mfma", "metric-f32-q8-fp32-mfma"])
+def test_sweep_is_deterministic_and_schedule_independent(eng, n, q, dtype, split):
     """The look-ahead runs the chain, the head and the tail updates of the sweep on two or three streams (three with
     q >= 4: the inverse-factor columns get their own chain); every tile still receives its updates in a fixed order, so
     (a) repeated factorisations must agree bit for bit over the WHOLE factor buffer (U, augmented column, W), and
     (b) they must agree bit for bit with the one-stream schedule (PLMC_SERIAL=1).  A race between the streams, or a
     store-data hazard in the tile write-back ("Write-back hazard": round 1's "wrong factors under the
     look-ahead" was exactly that and showed up here as thousands of differing tiles), fails this test.
-    With the default arithmetic of the fp32 path (bulk products on the bf16 matrix cores, bf3_engine.hpp: which tiles take
-    which engine does not depend on the schedule) and with PLMC_BF16X3=0 (fp32 MFMA everywhere)."""
+    With the default arithmetic of the fp32 path (bulk products as the two-plane fp16 split on the matrix cores,
+    bf3_engine.hpp: which tiles take which engine does not depend on the schedule), with the three-plane bf16 split
+    (PLMC_SPLIT=3) and with PLMC_SPLIT=0 (fp32 MFMA everywhere)."""
     import os
     import contextlib
     from projectedlmc import _hip
-    with (contextlib.nullcontext() if bf3 else _hip.knob("PLMC_BF16X3", "0")):
+    with (contextlib.nullcontext() if split == 2 else _hip.knob("PLMC_SPLIT", str(split))):
         _schedule_independence_body(eng, n, q, dtype)
         eng.free_workspaces()
 

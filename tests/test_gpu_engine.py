@@ -87,14 +87,17 @@ def _multi_group_body(eng, n, d, q):
 
 
 @pytest.mark.parametrize("n,d,q", [(1000, 8, 2), (2300, 12, 3), (4200, 5, 2)])
-def test_bf16_split_engine_against_fp32_mfma_path(eng, n, d, q):
-    """Default arithmetic of the fp32 path: the depth-1024 trailing updates of the sweep (from three groups of block rows
-    on) and the W^T W products of the gradient kernel run on the bf16 matrix cores from three-plane split operands (six
-    plane products into two fp32 accumulator levels, csrc/bf3_engine.hpp).  PLMC_BF16X3=0 runs the same products on
-    v_mfma_f32_16x16x4_f32.  Both must sit inside the fp32 tolerance against the fp64 oracle, and the split engine's error
-    must be of the size of the fp32 MFMA path's or below (the isolated product is 0.3-0.4 x, profiles/r03_split_numerics.txt;
-    through the ill-conditioned solve the two are different roundings of the same problem, so they are compared through the
-    oracle with a factor 2 + a few fp32 ulps of the largest magnitude, never with each other)."""
+def test_split_engines_against_fp32_mfma_path(eng, n, d, q):
+    """Arithmetic of the bulk fp32 products (the depth-1024 trailing updates and group panels of the sweep, from three groups
+    of block rows on, and the W^T W products of the gradient kernel; csrc/bf3_engine.hpp):
+      default (PLMC_SPLIT=2): two fp16 planes per operand, scaled by bounds from the diagonal and the noise, three plane
+                              products into two fp32 accumulator levels;
+      PLMC_SPLIT=3:           three bf16 planes, six plane products, two levels;
+      PLMC_SPLIT=0:           v_mfma_f32_16x16x4_f32 everywhere.
+    All must sit inside the fp32 tolerance against the fp64 oracle, and the split engines' errors must be of the size of the
+    fp32 MFMA path's or below (the isolated product is 0.3-0.45 x, profiles/r03_split_numerics.txt; through the
+    ill-conditioned solve these are different roundings of the same problem, so they are compared through the oracle with
+    a factor 2 + a few fp32 ulps of the largest magnitude, never with each other)."""
     from projectedlmc import _hip
     X, y, ell, noise, osc = _problem(n, d, q, seed=n + 1)
     ref = gm.exact_latent_log_prob_analytic("matern", X, ell, noise, y, None, 2.5)
@@ -108,15 +111,42 @@ def test_bf16_split_engine_against_fp32_mfma_path(eng, n, d, q):
         torch.cuda.synchronize()
         return [t.detach().cpu().double() for t in (lp, ell_d.grad, nz_d.grad, y_d.grad)]
 
-    split = run()
-    with _hip.knob("PLMC_BF16X3", "0"):
+    h2 = run()
+    with _hip.knob("PLMC_SPLIT", "3"):
+        b3 = run()
+    with _hip.knob("PLMC_SPLIT", "0"):
         plain = run()
-    for got, base, want, tol in ((split[0], plain[0], ref[0], 1e-4), (split[1], plain[1], ref[1], 2e-3),
-                                 (split[2], plain[2], ref[2], 2e-3), (split[3], plain[3], ref[4], 2e-3)):
-        scale = want.abs().max()
-        e_split, e_plain = (got - want).abs().max() / scale, (base - want).abs().max() / scale
-        assert e_split < tol and e_plain < tol, (e_split, e_plain)
-        assert e_split < 2.0 * e_plain + 2e-6, (e_split, e_plain)
+    for split in (h2, b3):
+        for got, base, want, tol in ((split[0], plain[0], ref[0], 1e-4), (split[1], plain[1], ref[1], 2e-3),
+                                     (split[2], plain[2], ref[2], 2e-3), (split[3], plain[3], ref[4], 2e-3)):
+            scale = want.abs().max()
+            e_split, e_plain = (got - want).abs().max() / scale, (base - want).abs().max() / scale
+            assert e_split < tol and e_plain < tol, (e_split, e_plain)
+            assert e_split < 2.0 * e_plain + 2e-6, (e_split, e_plain)
+
+
+def test_fp16_split_handles_extreme_scales(eng):
+    """The two-plane fp16 split scales its operands by bounds derived from the largest diagonal entry and the noise, so that
+    fp16 never overflows and small magnitudes keep their bits: tiny noise (W entries ~ 1 / sqrt(noise) large), large and
+    tiny output scales (U entries ~ sqrt(outputscale)), and targets of any size (the augmented columns stay on the fp32
+    MFMAs).  Same fp32 tolerance against the fp64 oracle as anywhere else."""
+    n, d = 2300, 6
+    dev = torch.device("cuda:0")
+    f = lambda t: t.to(dev, torch.float32)
+    for seed, nz, osv, ysc in ((1, 2e-3, 1.0, 1.0), (2, 80.0, 4e4, 300.0), (3, 2e-6, 1e-3, 1e-2), (4, 0.3, 1.0, 1e4)):
+        X, y, ell, noise, osc = _problem(n, d, 2, seed=seed)
+        noise = torch.full_like(noise, nz)
+        osc = torch.full_like(osc, osv)
+        y = y * ysc
+        ref = gm.exact_latent_log_prob_analytic("matern", X, ell, noise, y, osc, 2.5)
+        ell_d, nz_d, y_d, os_d = f(ell).requires_grad_(), f(noise).requires_grad_(), f(y).requires_grad_(), f(osc).requires_grad_()
+        lp = eng.exact_latent_log_prob("matern52", f(X), ell_d, os_d, nz_d, y_d)
+        lp.sum().backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(lp).all()
+        assert ((lp.detach().cpu().double() - ref[0]).abs() / ref[0].abs()).max() < 1e-4, (seed, lp, ref[0])
+        for got, want in ((ell_d.grad, ref[1]), (nz_d.grad, ref[2]), (os_d.grad, ref[3]), (y_d.grad, ref[4])):
+            assert (got.detach().cpu().double() - want).abs().max() < 2e-3 * want.abs().max(), seed
 
 
 @pytest.mark.parametrize("kind", ["rbf", "matern52"])
