@@ -143,25 +143,29 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
 }
 
 // ---- scales of the split engine's operand families (bf3_engine.hpp).  Per latent eight floats in the Vd scratch:
-enum { SC_SU = 0, SC_SW = 1, SC_RU = 2, SC_RW = 3, SC_N = 8 };
+enum { SC_SU = 0, SC_SW = 1, SC_RU = 2, SC_RW = 3, SC_SA = 4, SC_RA = 5, SC_N = 8 };
 //   SU solved rows, U columns:      |U_kj| <= sqrt(A_jj) <= sqrt(D),  D = largest diagonal entry of the input
 //   SW solved rows, W columns, and the inverse triangle Vgg:   |W_ij| <= ||U^-1||_2 = 1 / sqrt(lambda_min)
 //   RU raw rows (before their panel solve), U columns: entries of Schur complements, <= D
 //   RW raw rows, W columns:  -U[<g, R]^T W[<g, c],  <= ||U[:, j]||_2 ||W||_2 <= sqrt(D / lambda_min)
+//   SA solved rows, augmented columns:  z = U^-T r,  |z_i| <= ||W||_2 ||r||_2 <= R / sqrt(lambda_min),  R = sqrt(n) max |r_ij| >= the
+//      2-norm of every augmented column of the input
+//   RA raw rows, augmented columns:  r[R] - U[<g, R]^T z[<g],  <= R (1 + sqrt(D / lambda_min))
 // lambda_min is bounded below by the caller's `eig_lo` (the noise variance of a GP covariance) -- and by the smallest
 // diagonal entry, which brings in the identity padding of the rows beyond n (eigenvalue 1, whatever the noise).  SplitB3
 // needs no scales (all 1).  grid (q).
+constexpr int SCALE_NT = 1024;
 template <class S>
-__global__ __launch_bounds__(NTHREADS) void k_split_scales(const float *__restrict__ A, int64_t n_pad, int64_t lda, int64_t strideA,
+__global__ __launch_bounds__(SCALE_NT) void k_split_scales(const float *__restrict__ A, int64_t n_pad, int64_t lda, int64_t strideA, int naug_pad,
                                                            const float *__restrict__ eig_lo, float *__restrict__ sc, int64_t sc_stride) {
   const int lat = blockIdx.x;
   float *o = sc + (int64_t)lat * sc_stride;
   if constexpr (S::NPL == 3) {
     if (threadIdx.x < SC_N) o[threadIdx.x] = 1.0f;
   } else {
-    __shared__ float red[NTHREADS], redm[NTHREADS];
+    __shared__ float red[SCALE_NT], redm[SCALE_NT];
     float d = 0.0f, dm = 3.0e38f;
-    for (int64_t i = threadIdx.x; i < n_pad; i += NTHREADS) {
+    for (int64_t i = threadIdx.x; i < n_pad; i += SCALE_NT) {
       const float v = A[(int64_t)lat * strideA + i * lda + i];
       d = fmaxf(d, v);
       dm = fminf(dm, v);
@@ -169,22 +173,45 @@ __global__ __launch_bounds__(NTHREADS) void k_split_scales(const float *__restri
     red[threadIdx.x] = d;
     redm[threadIdx.x] = dm;
     __syncthreads();
-    for (int k = NTHREADS / 2; k > 0; k >>= 1) {
+    for (int k = SCALE_NT / 2; k > 0; k >>= 1) {
       if ((int)threadIdx.x < k) {
         red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + k]);
         redm[threadIdx.x] = fminf(redm[threadIdx.x], redm[threadIdx.x + k]);
       }
       __syncthreads();
     }
+    const float dmax = red[0], dmin = redm[0];
+    __syncthreads();
+    // largest |entry| of the augmented columns (whole 512-byte row pieces, 16 bytes per thread, 8 loads in flight); the bound of
+    // a column's 2-norm is sqrt(n_pad) times it -- a maximum, unlike a sum, does not depend on the order: the scales are
+    // the same in every run
+    float am = 0.0f;
+    const int cq = naug_pad / 4;                                      // 16-byte pieces per row
+    const int64_t items = (int64_t)n_pad * cq;
+    const float *Aa = A + (int64_t)lat * strideA + n_pad;
+#pragma unroll 8
+    for (int64_t w = threadIdx.x; w < items; w += SCALE_NT) {
+      const float4 v = *reinterpret_cast<const float4 *>(Aa + (w / cq) * lda + (w % cq) * 4);
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    red[threadIdx.x] = am;
+    __syncthreads();
+    for (int k = SCALE_NT / 2; k > 0; k >>= 1) {
+      if ((int)threadIdx.x < k) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + k]);
+      __syncthreads();
+    }
     if (threadIdx.x == 0) {
-      const float D = red[0] > 0.0f ? red[0] : 1.0f;
-      float lam = fminf(eig_lo[lat], redm[0]);             // (lambda_min <= every diagonal entry: still a lower bound)
+      const float D = dmax > 0.0f ? dmax : 1.0f;
+      const float Rn = sqrtf((float)n_pad) * red[0] + 1e-30f;   // >= the 2-norm of every augmented column (zero right-hand side: any scale will do)
+      float lam = fminf(eig_lo[lat], dmin);                // (lambda_min <= every diagonal entry: still a lower bound)
       if (!(lam > 1e-12f * D)) lam = 1e-12f * D;          // no usable bound: assume a condition number of 1e12
       o[SC_SU] = b3_scale_for(sqrtf(D));
       o[SC_SW] = b3_scale_for(1.0f / sqrtf(lam));
       o[SC_RU] = b3_scale_for(D);
       o[SC_RW] = b3_scale_for(sqrtf(D / lam));
-      o[4] = D; o[5] = lam; o[6] = 0.0f; o[7] = 0.0f;
+      o[SC_SA] = b3_scale_for(Rn / sqrtf(lam));
+      o[SC_RA] = b3_scale_for(Rn * (1.0f + sqrtf(D / lam)));
+      o[6] = D; o[7] = lam;
     }
   }
 }
@@ -202,7 +229,7 @@ __global__ __launch_bounds__(B3_NT, 2) void k_update_bf3(float *A, int64_t lda, 
                                                          ColMap<float> cm, int skip_ib, int skip_jb, const unsigned short *__restrict__ Pl,
                                                          int64_t pl_lat_stride, int64_t wcol0, unsigned short *__restrict__ Praw,
                                                          int64_t praw_lat_stride, int raw_end, const float *__restrict__ sc, int64_t sc_stride) {
-  if (ROLE == 3) __builtin_amdgcn_s_setprio(2);
+  if (ROLE == 2 || ROLE == 3) __builtin_amdgcn_s_setprio(2);
   __shared__ __align__(16) unsigned char lds[b3_lds_bytes<S>()];
   const int bx = blockIdx.x, ibm = ib0 + 2 * (int)blockIdx.y, lat = blockIdx.z;
   int kr0 = r_lo * NB, depth = (r_hi - r_lo + 1) * NB;
@@ -218,8 +245,10 @@ __global__ __launch_bounds__(B3_NT, 2) void k_update_bf3(float *A, int64_t lda, 
     v0 = jb >= ibm && !(ibm < skip_ib && jb < skip_jb);
     v1 = v1 && jb >= ibm + 1 && !(ibm + 1 < skip_ib && jb < skip_jb);
     col0 = colp = (int64_t)jb * NB;
-  } else if (bx < cm.nU + cm.Taug) {                                   // (SplitB3 only: SplitH2 launches carry no augmented tiles)
+  } else if (bx < cm.nU + cm.Taug) {
     col0 = colp = cm.n_pad + (int64_t)(bx - cm.nU) * NB;
+    sB = scl[SC_SA];
+    sRaw = scl[SC_RA];
   } else {
     const int cb = cm.w0 + bx - cm.nU - cm.Taug;
     Cb = cm.W + (int64_t)lat * cm.strideW;
@@ -306,30 +335,22 @@ __global__ __launch_bounds__(NTHREADS, (sizeof(T) == 8 || HEAD ? 2 : 4)) void k_
 }
 
 // Panel buffer -> factor buffer (block row g0 + i, column strip t of the column map).  grid (tiles, G, q); HBM-bound.
-template <typename T, class S = SplitB3>
+// (fp32 / fp64 engine only: the split engine's group panel works in place, k_gpanel_bf3.)
+template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_gpanel_copy(T *A, int64_t lda, int64_t strideA, int g0, ColMap<T> cm, const T *__restrict__ Pb,
-                                                          int64_t ldp, int64_t strideP, unsigned short *__restrict__ Pl, int64_t pl_lat_stride,
-                                                          int64_t wcol0, const float *__restrict__ sc, int64_t sc_stride) {
+                                                          int64_t ldp, int64_t strideP) {
   using vec_t = typename Traits<T>::vec_t;
   constexpr int EPV = Traits<T>::EPV, CPR = NB / EPV;
   const int lat = blockIdx.z, t = blockIdx.x, i = blockIdx.y;
   T *D;
-  int64_t ldd = lda, colp;                                 // colp: the strip's column in factor-buffer coordinates
-  if (t < cm.nU) { colp = (int64_t)(cm.u0 + t) * NB; D = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + colp; }
-  else if (t < cm.nU + cm.Taug) { colp = cm.n_pad + (int64_t)(t - cm.nU) * NB; D = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + colp; }
+  int64_t ldd = lda;
+  if (t < cm.nU) D = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + (int64_t)(cm.u0 + t) * NB;
+  else if (t < cm.nU + cm.Taug) D = A + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + cm.n_pad + (int64_t)(t - cm.nU) * NB;
   else {
     ldd = cm.ldw;
-    colp = wcol0 + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
     D = cm.W + (int64_t)lat * cm.strideW + (int64_t)(g0 + i) * NB * ldd + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
   }
   const T *Src = Pb + (int64_t)lat * strideP + (int64_t)i * NB * ldp + (int64_t)t * NB;
-  if constexpr (sizeof(T) == 4) {
-    if (Pl) {                                              // split engine: the finished rows also as k8-ordered planes
-      const float scale = sc[(int64_t)lat * sc_stride + (t < cm.nU + cm.Taug ? SC_SU : SC_SW)];
-      b3_split_block<S, true>(Src, ldp, Pl + (int64_t)lat * pl_lat_stride + b3_index<S>((int64_t)i * NB, 0, colp, lda), lda, scale, D, ldd, threadIdx.x);
-      return;
-    }
-  }
   for (int c = threadIdx.x; c < NB * CPR; c += NTHREADS) {
     const int r = c / CPR, col = (c % CPR) * EPV;
     *reinterpret_cast<vec_t *>(D + (int64_t)r * ldd + col) = *reinterpret_cast<const vec_t *>(Src + (int64_t)r * ldp + col);
@@ -418,7 +439,7 @@ __global__ __launch_bounds__(NTHREADS) void k_raw_planes(const float *__restrict
     colp = wcol0 + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
     Src = cm.W + (int64_t)lat * cm.strideW + (int64_t)(g0 + i) * NB * lds_ + (int64_t)(cm.w0 + t - cm.nU - cm.Taug) * NB;
   }
-  const float scale = sc[(int64_t)lat * sc_stride + (t < cm.nU + cm.Taug ? SC_RU : SC_RW)];
+  const float scale = sc[(int64_t)lat * sc_stride + (t < cm.nU ? SC_RU : (t < cm.nU + cm.Taug ? SC_RA : SC_RW))];
   b3_split_block<S, false>(Src, lds_, Praw + (int64_t)lat * praw_lat_stride + b3_index<S>((int64_t)i * NB, 0, colp, lda), lda, scale, nullptr, 0,
                            threadIdx.x);
 }
@@ -428,20 +449,23 @@ __global__ __launch_bounds__(NTHREADS) void k_raw_planes(const float *__restrict
 // rows (Praw: k_update_bf3 of the previous group / k_raw_planes).  The operands are read from plane buffers only, so the
 // result goes IN PLACE into the factor buffer -- no panel buffer, no copy kernel -- and, while the tile is in LDS, as planes
 // into the rolling buffer `Pl` for the trailing updates.  A workgroup takes the macro rows (2 a, 2 a + 1) at the depth of
-// the second (the block Vgg[2 a + 1][2 a] is zero in VgP), heavy and light macro rows paired: y and nm - 1 - y.
+// the second (the block Vgg[2 a + 1][2 a] is zero in VgP), heavy and light macro rows paired: y and nm - 1 - y (`paired`; the
+// latency-critical launch over the few columns of the next group takes one macro row per workgroup instead).
 // Accuracy: the product with the inverse triangle cancels; tools/split_numerics_probe.hip holds that case (0.37 x the error
-// of the fp32 MFMA chain).  grid (tiles, (nm + 1) / 2, q), nm = (G + 1) / 2.
+// of the fp32 MFMA chain).  grid (tiles, paired ? (nm + 1) / 2 : nm, q), nm = (G + 1) / 2.
 template <class S>
 __global__ __launch_bounds__(B3_NT, 2) void k_gpanel_bf3(float *A, int64_t lda, int64_t strideA, int g0, int G, ColMap<float> cm,
                                                          const unsigned short *__restrict__ VgP, int64_t vgp_lat_stride,
                                                          const unsigned short *__restrict__ Praw, int64_t praw_lat_stride,
                                                          unsigned short *__restrict__ Pl, int64_t pl_lat_stride, int64_t wcol0,
-                                                         const float *__restrict__ sc, int64_t sc_stride) {
+                                                         const float *__restrict__ sc, int64_t sc_stride, int paired) {
+  if (!paired) __builtin_amdgcn_s_setprio(2);                         // the head columns: the next chain waits for them
   __shared__ __align__(16) unsigned char lds[b3_lds_bytes<S>()];
   const int lat = blockIdx.z, t = blockIdx.x, y = blockIdx.y;
   const float *scl = sc + (int64_t)lat * sc_stride;
-  const bool wfam = t >= cm.nU + cm.Taug;                              // W columns: raw scale RW, solved scale SW
-  const float unscale = 1.0f / (scl[SC_SW] * scl[wfam ? SC_RW : SC_RU]), pscale = scl[wfam ? SC_SW : SC_SU];
+  const int fam = t < cm.nU ? 0 : (t < cm.nU + cm.Taug ? 2 : 1);       // U / W / augmented columns: raw scale RU / RW / RA, solved SU / SW / SA
+  const float unscale = 1.0f / (scl[SC_SW] * scl[fam == 0 ? SC_RU : (fam == 1 ? SC_RW : SC_RA)]);
+  const float pscale = scl[fam == 0 ? SC_SU : (fam == 1 ? SC_SW : SC_SA)];
   float *D;
   int64_t ldd = lda, colp;
   if (t < cm.nU) { colp = (int64_t)(cm.u0 + t) * NB; D = A + (int64_t)lat * strideA + (int64_t)g0 * NB * lda + colp; }
@@ -457,7 +481,7 @@ __global__ __launch_bounds__(B3_NT, 2) void k_gpanel_bf3(float *A, int64_t lda, 
   const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), tid = (int)threadIdx.x & 255;
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
-    const int a = pass == 0 ? nm - 1 - y : (y < nm - 1 - y ? y : -1);
+    const int a = pass == 0 ? nm - 1 - y : ((paired && y < nm - 1 - y) ? y : -1);
     if (a < 0) break;
     const int i0 = 2 * a, rows = G - i0 < 2 ? G - i0 : 2;
     Acc<float> acc0, acc1;
@@ -616,7 +640,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
                int with_inverse, int q, const float *eig_lo, void *stream) {
   constexpr bool bf3 = !std::is_void<S>::value;
   using SS = typename std::conditional<bf3, S, SplitB3>::type;       // a valid scheme type for the (dead) template arguments when bf3 is off
-  constexpr bool aug_fp32 = bf3 && SS::NPL == 2;                       // SplitH2 has no a-priori bound for the augmented columns: fp32 engine
+  constexpr bool aug_fp32 = false;                                     // (the augmented columns have bounds too: k_split_scales)
   PLMC_REQUIRE(A && Vd && logdet && info, "null pointer");
   PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0 && lda % NB == 0 && lda >= n_pad, "n_pad/lda must be multiples of NB");
   const int64_t naug_pad = plmc_pad(naug);
@@ -722,7 +746,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     // Split engine: which engine a tile goes through must not depend on the schedule (bit-identical results with and
     // without the look-ahead): every tail / head tile takes the split engine on macro tiles, the next group's triangle
     // (U1; `crit`) and the chain stay on the fp32 MFMAs -- and so do the augmented columns under SplitH2 (aug_fp32)
-    const bool use_bf3 = bf3 && (cls == PK_TRAIL || (cls == PK_TRAIL_HEAD && !crit));
+    const bool use_bf3 = bf3 && (cls == PK_TRAIL || cls == PK_TRAIL_HEAD);
     const unsigned dyn = (cls == PK_TRAIL || (cls == PK_TRAIL_HEAD && !crit)) ? bulk_lds : 0u;
     auto fp32_launch = [&](const ColMap<T> &c) {
       const int cn = c.nU + c.Taug + c.nW;
@@ -748,6 +772,9 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
           if (cls == PK_TRAIL)
             hipLaunchKernelGGL((k_update_bf3<SS, 0>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cb, skip_ib, skip_jb, pl, pl_lat,
                                wcol0, Praw, pl_lat, raw_end, (const float *)scl, sc_lat);
+          else if (crit)
+            hipLaunchKernelGGL((k_update_bf3<SS, 2>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cb, skip_ib, skip_jb, pl, pl_lat,
+                               wcol0, Praw, pl_lat, raw_end, (const float *)scl, sc_lat);
           else
             hipLaunchKernelGGL((k_update_bf3<SS, 3>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cb, skip_ib, skip_jb, pl, pl_lat,
                                wcol0, Praw, pl_lat, raw_end, (const float *)scl, sc_lat);
@@ -764,9 +791,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     if (nt == 0) return;
     const double prods = G * (G + 1) / 2.0;               // 128-deep tile products per column strip
     ProfScope ps(PK_GPANEL, s, q * (double)nt * prods * 2.0 * nb3, q * (double)nt * (prods + G) * nb * nb * esz);
-    // fp32 engine: out of place into a panel buffer + copy (the copy also writes the planes of the solved rows when the
-    // split engine is on: the head columns R1 feed the tail / head updates as operands)
-    auto fp32_panel = [&](const ColMap<T> &c, bool with_planes) {
+    // fp32 / fp64 engine: out of place into a panel buffer + copy
+    auto fp32_panel = [&](const ColMap<T> &c) {
       const int ct = c.nU + c.Taug + c.nW;
       if (ct == 0) return;
       T *Pb = head ? Ph : Pbulk;
@@ -777,22 +803,20 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       else
         hipLaunchKernelGGL((k_gpanel_rows<T, 0>), dim3(ct, (G + 1) / 2, q), dim3(NTHREADS), bulk_lds, s, (const T *)A, lda, strideA, g0, G, c, Vg,
                            (int64_t)LDG, strideV, Pb, ldp, strideV);
-      hipLaunchKernelGGL((k_gpanel_copy<T, SS>), dim3(ct, G, q), dim3(NTHREADS), 0, s, A, lda, strideA, g0, c, (const T *)Pb, ldp, strideV,
-                         with_planes ? planes(g0) : (unsigned short *)nullptr, pl_lat, wcol0, (const float *)scl, sc_lat);
+      hipLaunchKernelGGL((k_gpanel_copy<T>), dim3(ct, G, q), dim3(NTHREADS), 0, s, A, lda, strideA, g0, c, (const T *)Pb, ldp, strideV);
     };
-    if constexpr (bf3) {
-      if (!head) {                                         // split engine, in place, planes from the epilogue (k_gpanel_bf3)
-        ColMap<T> cb = cm, ca = cm;
-        if (aug_fp32) { cb.Taug = 0; ca.nU = 0; ca.nW = 0; }
-        const int nb_ = cb.nU + cb.Taug + cb.nW, nm = (G + 1) / 2;
-        if (nb_ > 0)
-          hipLaunchKernelGGL((k_gpanel_bf3<SS>), dim3(nb_, (nm + 1) / 2, q), dim3(B3_NT), 0, s, A, lda, strideA, g0, G, cb, (const unsigned short *)VgP,
-                             pl_lat, (const unsigned short *)Praw, pl_lat, planes(g0), pl_lat, wcol0, (const float *)scl, sc_lat);
-        if (aug_fp32) fp32_panel(ca, false);
-        return;
-      }
+    if constexpr (bf3) {                                   // split engine, in place, planes from the epilogue (k_gpanel_bf3)
+      ColMap<T> cb = cm, ca = cm;
+      if (aug_fp32) { cb.Taug = 0; ca.nU = 0; ca.nW = 0; }
+      const int nb_ = cb.nU + cb.Taug + cb.nW, nm = (G + 1) / 2;
+      if (nb_ > 0)
+        hipLaunchKernelGGL((k_gpanel_bf3<SS>), dim3(nb_, head ? nm : (nm + 1) / 2, q), dim3(B3_NT), 0, s, A, lda, strideA, g0, G, cb,
+                           (const unsigned short *)VgP, pl_lat, (const unsigned short *)Praw, pl_lat, planes(g0), pl_lat, wcol0, (const float *)scl, sc_lat,
+                           head ? 0 : 1);
+      if (aug_fp32) fp32_panel(ca);
+      return;
     }
-    fp32_panel(cm, bf3);
+    fp32_panel(cm);
   };
 
   // whole-sweep bracket on the caller's stream (the per-kernel records of overlapped kernels add up to
@@ -803,7 +827,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   hipLaunchKernelGGL(k_zero_diag_out<T>, dim3(m > GMAX ? m : GMAX, q), dim3(NTHREADS), 0, st, Vd, strideV, m, Wg, (int64_t)LDG,
                      strideV, (int64_t)NB * LDG + NB, GMAX);
   if constexpr (bf3)                                      // scales of the operand families (SplitB3: ones), before anything splits
-    hipLaunchKernelGGL((k_split_scales<SS>), dim3(q), dim3(NTHREADS), 0, st, (const float *)A, n_pad, lda, strideA, eig_lo, scl, sc_lat);
+    hipLaunchKernelGGL((k_split_scales<SS>), dim3(q), dim3(SCALE_NT), 0, st, (const float *)A, n_pad, lda, strideA, (int)naug_pad, eig_lo, scl, sc_lat);
   auto finish = [&]() {
     hipLaunchKernelGGL(k_logdet<T>, dim3(q), dim3(NTHREADS), 0, st, (const T *)A, n_pad, lda, strideA, logdet, info);
     return launch_status("potrf_impl");
@@ -900,7 +924,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     // one stream: chain -> transpose -> group panel over every column -> trailing update of every row below
     // PLMC_BF16X3: which engine a tile goes through must not depend on the schedule -- as under the look-ahead, the panel
     // columns of the next group and its triangle update (U1) take the fp32 MFMAs, everything else the bf16 engine
-    raw_planes0(st, G0(2));
+    raw_planes0(st, G0(1));
     for (int gi = 0; gi < ng; ++gi) {
       const int g0 = G0(gi), g1 = G0(gi + 1);
       chain(gi, st);
@@ -940,14 +964,16 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   (void)hipEventRecord(e_entry, st);
   (void)hipStreamWaitEvent(C, e_entry, 0);
   (void)hipStreamWaitEvent(H, e_entry, 0);
-  raw_planes0(H, G0(2));
+  raw_planes0(H, G0(1));                                                        // (the head panel of the first group waits for it: e_hd)
+  (void)hipEventRecord(e_hd, H);
   for (int gi = 0; gi < ng; ++gi) {
     const int g0 = G0(gi), g1 = G0(gi + 1), g2 = G0(gi + 2), G = g1 - g0;
     const T *Vg = Vg2[gi & 1];
     chain(gi, C);
     vtrans(gi, C);
+    vg_planes(gi, C);                                                           // planes of Vgg: both panels read them
     (void)hipEventRecord(e_v, C);
-    if (gi > 0) (void)hipStreamWaitEvent(C, e_hd, 0);                          // head(gi - 1): rows R0 final
+    if (gi > 0 || bf3) (void)hipStreamWaitEvent(C, e_hd, 0);                   // head(gi - 1): rows R0 final (split engine: and their raw planes)
     gpanel(g0, G, cm_buf(g1, g2 - g1, 0, 0, 0), Vg, C, 1);                      // head columns R1
     (void)hipEventRecord(e_gh, C);
     if (gi > 0) (void)hipStreamWaitEvent(C, e_tail, 0);                        // tail(gi - 1): rows R1 up to date
@@ -955,7 +981,6 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
 
     (void)hipStreamWaitEvent(H, e_v, 0);
     wtri_planes(gi, H);
-    vg_planes(gi, H);
     gpanel(g0, G, cm_buf(g2, m - g2, Taug, 0, g0), Vg, H, 0);                   // rest of the panel columns
     (void)hipEventRecord(e_p, H);
     (void)hipStreamWaitEvent(H, e_gh, 0);

@@ -34,13 +34,16 @@ def span(d, key, s, e):
         d[key] = [s, e]
 # bulk kernels: attribute to groups in order of appearance per class
 cls_of = lambda n: ("gp_head" if n.startswith("k_gpanel_rows<float, 1") or n.startswith("k_gpanel_rows<double, 1") else
-                    "gp_rest" if n.startswith("k_gpanel_rows") else
+                    "gp_rest" if n.startswith("k_gpanel_rows") or n.startswith("k_gpanel_bf3") else
                     "U1" if n.startswith("k_update<float, 2") or n.startswith("k_update<double, 2") else
-                    "head" if n.startswith("k_update_bf3<3") or n.startswith("k_update<float, 3") or n.startswith("k_update<double, 3") else
-                    "tail" if n.startswith("k_update_bf3<0") or n.startswith("k_update<float, 0") or n.startswith("k_update<double, 0") else None)
+                    "head" if (n.startswith("k_update_bf3<") and n.endswith(" 3>")) or n.startswith("k_update<float, 3") or n.startswith("k_update<double, 3") else
+                    "tail" if (n.startswith("k_update_bf3<") and n.endswith(" 0>")) or n.startswith("k_update<float, 0") or n.startswith("k_update<double, 0") else None)
 cnt = {}
-for name, s, e, q in ev:
+split_on = any("_bf3<" in name for name, *_ in ev)      # split engine: its launches define the phases; the fp32 launches of the
+for name, s, e, q in ev:                                 # same class only carry the augmented columns
     c = cls_of(name)
+    if split_on and c in ("gp_rest", "head", "tail") and "_bf3<" not in name:
+        continue
     if c is None:
         continue
     i = cnt.get(c, 0); cnt[c] = i + 1
