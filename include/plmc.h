@@ -134,6 +134,17 @@ int plmc_potrf_ex_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t s
                       int *info, int with_inverse, int q, const double *eig_lo, void *stream);
 
 /*
+ * Forward substitution of NEW augmented columns against a buffer that plmc_potrf_* already factorised with
+ * with_inverse != 0 (and has not been modified since):  columns [n_pad, n_pad + naug) <- U^-T columns.  wcol0 = first
+ * inverse-factor column of that factorisation (n_pad + plmc_pad(naug of the factorisation)); naug here may be smaller.
+ * What an eval-mode model does on its second and later calls (projected_lmc.py:1133-1134: gpytorch's prediction strategy
+ * keeps the factorisation across calls): n^2 naug flops instead of a new sweep.  Vd: the scratch of the factorisation
+ * (its group workspace is reused).
+ */
+int plmc_potrs_aug_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int64_t strideA, float *Vd, int q, void *stream);
+int plmc_potrs_aug_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int64_t strideA, double *Vd, int q, void *stream);
+
+/*
  * Gather augmented column c of every latent into a contiguous vector z (q x n_pad) and return
  * quad[latent] = sum z^2 in double (the inv_quad term of MVN.log_prob, :1201).
  */

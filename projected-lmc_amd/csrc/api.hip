@@ -17,7 +17,7 @@ char *err_buf() {
 static const char *kProfNames[PK_COUNT] = {"k_assemble", "k_write_rhs", "k_assemble_cross", "k_diag",   "k_panel",
                                            "k_trail",    "k_wdiag",     "k_trtri_row",      "k_extract_col",
                                            "k_wt_matvec", "k_kinv_grad", "k_reduce_grad", "k_kernel_vjp",
-                                           "sweep_total", "k_trail_row", "k_trail_head", "k_gpanel", "k_kacc", "k_grad_tiles", "k_split_w"};
+                                           "sweep_total", "k_trail_row", "k_trail_head", "k_gpanel", "k_kacc", "k_grad_tiles", "k_split_w", "k_posterior_moments"};
 struct ProfRec { int id; hipEvent_t a, b; double flops, bytes; };
 static unsigned g_prof_mask = 0;          // bit i: bracket kernel class i
 static std::vector<ProfRec> g_recs;

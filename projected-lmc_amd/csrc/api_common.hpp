@@ -32,7 +32,7 @@ inline int launch_status(const char *fn) {
 
 // kernel classes known to the optional profiler (api.hip)
 enum ProfKernel { PK_ASSEMBLE, PK_WRITE_RHS, PK_CROSS, PK_DIAG, PK_PANEL, PK_TRAIL, PK_WDIAG, PK_TRTRI, PK_EXTRACT,
-                  PK_WTMV, PK_KINV_GRAD, PK_REDUCE, PK_VJP, PK_SWEEP, PK_TRAIL_ROW, PK_TRAIL_HEAD, PK_GPANEL, PK_KACC, PK_GRAD_TILES, PK_SPLIT, PK_COUNT };
+                  PK_WTMV, PK_KINV_GRAD, PK_REDUCE, PK_VJP, PK_SWEEP, PK_TRAIL_ROW, PK_TRAIL_HEAD, PK_GPANEL, PK_KACC, PK_GRAD_TILES, PK_SPLIT, PK_POST, PK_COUNT };
 
 // Brackets the launches made while it is alive with two hipEvents (no-op unless its class is enabled, plmc_prof_enable).
 // flops / bytes = ALGORITHMIC work of the bracketed launch (DESIGN.md gives the formulas).

@@ -179,29 +179,48 @@ __global__ void k_write_rhs(const T *__restrict__ rhs, int nrhs, int n, T *__res
   }
 }
 
-// Out[i][col0 + j] = os * k(x_i, xs_j); block = 64 (j) x 4 (i).
-template <typename T>
+// Out[i][col0 + j] = os * k(x_i, xs_j).  Workgroup = 256 test points (one per thread, its scaled coordinates in registers) x
+// CROSS_ROWS training points (scaled coordinates staged in LDS, read as broadcasts); every row of the block is one 1 KB
+// store.  grid (ceil(ns / 256), ceil(n_rows / CROSS_ROWS), q).  Rows n .. n_rows - 1 (padding) are written as zeros.
+constexpr int CROSS_ROWS = 32;
+template <typename T, int DCAP>
 __global__ __launch_bounds__(NTHREADS) void k_assemble_cross(int kind, const T *__restrict__ X, int n,
                                                               const T *__restrict__ Xs, int ns, int d,
                                                               const T *__restrict__ ell, const T *__restrict__ oscale,
                                                               T *__restrict__ A, int64_t n_rows, int64_t lda,
                                                               int64_t strideA, int64_t col0) {
+  __shared__ T xi[CROSS_ROWS][DCAP + 1];
   const int lat = blockIdx.z;
-  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int64_t i = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (j >= ns || i >= n_rows) return;
+  const int j = blockIdx.x * NTHREADS + threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.y * CROSS_ROWS;
   const T *el = ell + (int64_t)lat * d;
-  T val = T(0);
-  if (i < n) {
-    T r2 = T(0), sp = T(1);
-    for (int k = 0; k < d; ++k) {
-      T df = (X[i * d + k] - Xs[(int64_t)j * d + k]) / el[k];
-      r2 += df * df;
-      if (kind == K_SPLINE) sp *= spline_factor(X[i * d + k] / el[k], Xs[(int64_t)j * d + k] / el[k]);
-    }
-    val = (oscale ? oscale[lat] : T(1)) * (kind == K_SPLINE ? sp : kern_value<T>(kind, r2));
+  for (int e = threadIdx.x; e < CROSS_ROWS * DCAP; e += NTHREADS) {
+    const int r = e / DCAP, k = e % DCAP;
+    xi[r][k] = (k < d && i0 + r < n) ? X[(i0 + r) * d + k] / el[k] : T(0);
   }
-  A[(int64_t)lat * strideA + i * lda + col0 + j] = val;
+  T xs[DCAP];
+#pragma unroll
+  for (int k = 0; k < DCAP; ++k) xs[k] = (k < d && j < ns) ? Xs[(int64_t)j * d + k] / el[k] : T(0);
+  const T os = oscale ? oscale[lat] : T(1);
+  __syncthreads();
+  if (j >= ns) return;
+  T *out = A + (int64_t)lat * strideA + i0 * lda + col0 + j;
+#pragma unroll 4
+  for (int r = 0; r < CROSS_ROWS; ++r) {
+    if (i0 + r >= n_rows) break;
+    T val = T(0);
+    if (i0 + r < n) {
+      T r2 = T(0), sp = T(1);
+#pragma unroll
+      for (int k = 0; k < DCAP; ++k) {
+        const T df = xi[r][k] - xs[k];
+        r2 += df * df;
+        if (kind == K_SPLINE && k < d) sp *= spline_factor(xi[r][k], xs[k]);
+      }
+      val = os * (kind == K_SPLINE ? sp : kern_value<T>(kind, r2));
+    }
+    out[(int64_t)r * lda] = val;
+  }
 }
 
 template <typename T>
@@ -253,8 +272,14 @@ int assemble_cross_impl(int kind, const T *X, int n, const T *Xs, int ns, int d,
   PLMC_REQUIRE(n > 0 && ns > 0 && q > 0 && d > 0 && d <= MAX_DIM, "bad sizes");
   PLMC_REQUIRE(n_rows >= n && col0 >= 0 && col0 + ns <= ldo, "cross block exceeds the output buffer");
   ProfScope ps(PK_CROSS, (hipStream_t)stream, 0.0, q * (double)n_rows * ns * sizeof(T));
-  hipLaunchKernelGGL(k_assemble_cross<T>, dim3((ns + 63) / 64, (unsigned)((n_rows + 3) / 4), q), dim3(NTHREADS), 0,
-                     (hipStream_t)stream, kind, X, n, Xs, ns, d, ell, oscale, Out, n_rows, ldo, strideO, col0);
+  const dim3 grid((ns + NTHREADS - 1) / NTHREADS, (unsigned)((n_rows + CROSS_ROWS - 1) / CROSS_ROWS), q);
+#define PLMC_CROSS(DC) \
+  hipLaunchKernelGGL((k_assemble_cross<T, DC>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, kind, X, n, Xs, ns, d, ell, oscale, Out, n_rows, ldo, strideO, col0)
+  if (d <= 4) PLMC_CROSS(4);
+  else if (d <= 8) PLMC_CROSS(8);
+  else if (d <= 16) PLMC_CROSS(16);
+  else PLMC_CROSS(32);
+#undef PLMC_CROSS
   return launch_status(__func__);
 }
 

@@ -13,28 +13,58 @@
 
 namespace plmc {
 
-// grid (ceil(ns / 64), q), 256 threads = 64 columns x 4 row groups
+// grid (ceil((1 + ns) / (16 EPV)), q), 256 threads = 16 column groups of EPV = 16 bytes x 16 row groups; every thread walks its
+// rows 8 at a time (8 x 16-byte loads in flight per thread; a workgroup reads 256-byte row pieces of 128 rows at once).  Few
+// columns per workgroup: with one latent per rank (the sharded runs) the column groups are all the parallelism there is.
+// The augmented block starts at the 16-byte-aligned column n_pad: its column 0 is z, column 1 + s is v(s).
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_posterior_moments(const T *__restrict__ A, int64_t n_pad, int64_t lda, int64_t strideA, int ns,
                                                                 T *__restrict__ mean, T *__restrict__ vsq) {
-  __shared__ double red[2][4][64];
-  const int lat = blockIdx.y, c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int s = blockIdx.x * 64 + c;
-  const T *Z = A + (int64_t)lat * strideA + n_pad;          // column n_pad: z; columns n_pad + 1 + s: v(s)
-  double m = 0.0, v2 = 0.0;
-  if (s < ns) {
-    for (int64_t r = rg; r < n_pad; r += 4) {
-      const double z = (double)Z[r * lda], v = (double)Z[r * lda + 1 + s];
-      m += v * z;
-      v2 += v * v;
+  using vec_t = typename Traits<T>::vec_t;
+  constexpr int EPV = Traits<T>::EPV, UNR = 8, CG = 16, RG = NTHREADS / CG;
+  __shared__ double red[2][RG][CG][EPV];
+  const int lat = blockIdx.y, cg = threadIdx.x % CG, rg = threadIdx.x / CG;
+  const int c0 = (blockIdx.x * CG + cg) * EPV;                  // first augmented column of this thread
+  const T *Z = A + (int64_t)lat * strideA + n_pad;              // column 0 of the augmented block
+  double m[EPV], v2[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) m[e] = v2[e] = 0.0;
+  if (c0 < 1 + ns) {
+    for (int64_t r0 = rg; r0 < n_pad; r0 += RG * UNR) {
+      vec_t v[UNR];
+      T z[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int64_t r = r0 + RG * u;
+        const bool ok = r < n_pad;
+        v[u] = ok ? *reinterpret_cast<const vec_t *>(Z + r * lda + c0) : vec_t{};
+        z[u] = ok ? Z[r * lda] : T(0);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+          const double x = (double)v[u][e];
+          m[e] += x * (double)z[u];
+          v2[e] += x * x;
+        }
     }
   }
-  red[0][rg][c] = m;
-  red[1][rg][c] = v2;
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) { red[0][rg][cg][e] = m[e]; red[1][rg][cg][e] = v2[e]; }
   __syncthreads();
-  if (rg == 0 && s < ns) {
-    mean[(int64_t)lat * ns + s] = (T)(red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    vsq[(int64_t)lat * ns + s] = (T)(red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  if (rg == 0) {
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const int s = c0 + e - 1;                                  // test point of augmented column c0 + e
+      if (s >= 0 && s < ns) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int g = 0; g < RG; ++g) { a += red[0][g][cg][e]; b += red[1][g][cg][e]; }
+        mean[(int64_t)lat * ns + s] = (T)a;
+        vsq[(int64_t)lat * ns + s] = (T)b;
+      }
+    }
   }
 }
 
@@ -60,8 +90,9 @@ int posterior_moments_impl(const T *A, int64_t n_pad, int64_t lda, int64_t strid
   PLMC_REQUIRE(A && mean && vsq, "null pointer");
   PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0 && ns > 0 && q > 0 && lda >= n_pad + 1 + ns, "bad sizes (lda must hold the 1 + ns augmented columns)");
   const double bytes = (double)q * n_pad * (1.0 + ns) * sizeof(T);
-  ProfScope ps(PK_EXTRACT, (hipStream_t)stream, 0.0, bytes);
-  hipLaunchKernelGGL(k_posterior_moments<T>, dim3((ns + 63) / 64, q), dim3(NTHREADS), 0, (hipStream_t)stream, A, n_pad, lda, strideA, ns, mean, vsq);
+  ProfScope ps(PK_POST, (hipStream_t)stream, 0.0, bytes);
+  constexpr int CPW = 16 * Traits<T>::EPV;                      // augmented columns per workgroup
+  hipLaunchKernelGGL(k_posterior_moments<T>, dim3((1 + ns + CPW - 1) / CPW, q), dim3(NTHREADS), 0, (hipStream_t)stream, A, n_pad, lda, strideA, ns, mean, vsq);
   return launch_status(__func__);
 }
 

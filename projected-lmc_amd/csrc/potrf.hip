@@ -360,15 +360,17 @@ __global__ __launch_bounds__(NTHREADS) void k_gpanel_copy(T *A, int64_t lda, int
 // Transpose of the group's inverse triangle: Vg[k][i] = Wg[i][k]^T for block pairs k <= i < G (Vg = Ugg^-1, upper,
 // K-major for the tile engine) and, when the inverse factor is wanted, the copy of Wg[i][k] into the factor buffer's
 // W columns (block row g0 + i, block column g0 + k).  grid (G (G + 1) / 2, q), 32 x 32 sub-tiles through LDS.
+// (`Wg` with leading dimension lds_ and batch stride strideS: the group scratch in the sweep; the W columns of a finished
+// factor buffer in plmc_potrs_aug.)
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, int64_t strideG, T *__restrict__ Vg, int G, T *Wout,
-                                                     int64_t ldw, int64_t strideW) {
+__global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, int64_t lds_, int64_t strideS, int64_t strideG, T *__restrict__ Vg, int G,
+                                                     T *Wout, int64_t ldw, int64_t strideW) {
   __builtin_amdgcn_s_setprio(3);
   __shared__ T tile[32][33];
   const int lat = blockIdx.y;
   int i = 0, k = (int)blockIdx.x;                    // blockIdx.x enumerates (i, k <= i) row by row
   while (k > i) { k -= i + 1; ++i; }
-  const T *src = Wg + (int64_t)lat * strideG + (int64_t)i * NB * LDG + (int64_t)k * NB;
+  const T *src = Wg + (int64_t)lat * strideS + (int64_t)i * NB * lds_ + (int64_t)k * NB;
   T *dst = Vg + (int64_t)lat * strideG + (int64_t)k * NB * LDG + (int64_t)i * NB;
   T *wo = Wout ? Wout + (int64_t)lat * strideW + (int64_t)i * NB * ldw + (int64_t)k * NB : nullptr;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, i
     for (int bk = 0; bk < NB; bk += 32) {
 #pragma unroll
       for (int r = 0; r < 32; r += 8) {
-        const T v = src[(int64_t)(bi + ty + r) * LDG + bk + tx];
+        const T v = src[(int64_t)(bi + ty + r) * lds_ + bk + tx];
         tile[ty + r][tx] = v;
         if (wo) wo[(int64_t)(bi + ty + r) * ldw + bk + tx] = v;
       }
@@ -872,7 +874,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   auto vtrans = [&](int gi, hipStream_t s) {
     const int g0 = G0(gi), G = G0(gi + 1) - g0;
     T *wo = WA ? WA + (int64_t)g0 * NB * lda + (int64_t)g0 * NB : (T *)nullptr;
-    hipLaunchKernelGGL((k_vtrans<T>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)Wg, strideV, Vg2[gi & 1], G, wo, lda, strideA);
+    hipLaunchKernelGGL((k_vtrans<T>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)Wg, (int64_t)LDG, strideV, strideV, Vg2[gi & 1], G, wo,
+                       lda, strideA);
   };
   // PLMC_BF16X3: planes of the group's inverse triangle (read back from the W columns k_vtrans wrote; any stream behind it)
   auto wtri_planes = [&](int gi, hipStream_t s) {
@@ -1002,6 +1005,48 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   return finish();
 }
 
+// Forward substitution of NEW augmented columns against a factor buffer that plmc_potrf_* already factorised WITH the inverse
+// factor: aug <- U^-T aug for the first naug augmented columns.  What an eval-mode model does on its second and later calls
+// (projected_lmc.py:1133-1134: gpytorch's prediction strategy keeps the factorisation): n^2 naug flops instead of a new sweep.
+// Per group of block rows: the group's inverse triangle W[R][R] (in the W columns) is transposed into the Vg scratch, the
+// group panel solves the rows R of the augmented columns, one depth-(128 G) update takes them out of the rows below.
+// MFMA of the element type (no planes of the factor exist any more); one stream.  wcol0 = first inverse-factor column.
+template <typename T>
+int potrs_aug_at(T *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int64_t strideA, T *Vd, int q, void *stream) {
+  PLMC_REQUIRE(A && Vd, "null pointer");
+  PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0 && lda % NB == 0 && wcol0 % NB == 0, "n_pad / lda / wcol0 must be multiples of NB");
+  const int64_t naug_pad = plmc_pad(naug);
+  PLMC_REQUIRE(naug > 0 && q > 0 && n_pad + naug_pad <= wcol0 && wcol0 + n_pad <= lda, "augmented columns must fit between the square part and the W columns");
+  PLMC_REQUIRE(aligned16(A) && aligned16(Vd), "unaligned buffer");
+  const hipStream_t st = (hipStream_t)stream;
+  const int m = (int)(n_pad / NB), Tu = (int)(naug_pad / NB);
+  const int64_t strideV = plmc_vd_blocks_for(n_pad, lda, (int)sizeof(T)) * (int64_t)NB * NB;
+  const double nb = (double)NB, nb3 = nb * nb * nb, esz = sizeof(T);
+  T *const Wg = Vd + (int64_t)m * NB * NB;
+  T *const Vg = Wg + (int64_t)GMAX * NB * LDG;
+  T *const Pbulk = Wg + 4 * (int64_t)GMAX * NB * LDG;
+  T *const WA = A + wcol0;
+  const ColMap<T> cm{0, 0, Tu, 0, 0, n_pad, (T *)nullptr, lda, strideA};
+  for (int g0 = 0; g0 < m; g0 += GMAX) {
+    const int g1 = g0 + GMAX < m ? g0 + GMAX : m, G = g1 - g0;
+    hipLaunchKernelGGL((k_vtrans<T>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, st, (const T *)(WA + (int64_t)g0 * NB * lda + (int64_t)g0 * NB), lda,
+                       strideA, strideV, Vg, G, (T *)nullptr, lda, strideA);
+    {
+      const double prods = G * (G + 1) / 2.0;
+      ProfScope ps(PK_GPANEL, st, q * (double)Tu * prods * 2.0 * nb3, q * (double)Tu * (prods + G) * nb * nb * esz);
+      hipLaunchKernelGGL((k_gpanel_rows<T, 0>), dim3(Tu, (G + 1) / 2, q), dim3(NTHREADS), 0, st, (const T *)A, lda, strideA, g0, G, cm, (const T *)Vg,
+                         (int64_t)LDG, strideV, Pbulk, lda, strideV);
+      hipLaunchKernelGGL((k_gpanel_copy<T>), dim3(Tu, G, q), dim3(NTHREADS), 0, st, A, lda, strideA, g0, cm, (const T *)Pbulk, lda, strideV);
+    }
+    if (g1 < m) {
+      const double tiles = (double)Tu * (m - g1);
+      ProfScope ps(PK_TRAIL, st, q * tiles * 2.0 * nb * nb * (G * nb), q * 2.0 * tiles * nb * nb * esz);
+      hipLaunchKernelGGL((k_update<T, 0, 4>), dim3(Tu, m - g1, q), dim3(NTHREADS), 0, st, A, lda, strideA, g1, g0, g1 - 1, cm, 0, 0);
+    }
+  }
+  return launch_status("plmc_potrs_aug");
+}
+
 template <typename T>
 int extract_col_impl(const T *A, int64_t n_pad, int64_t lda, int64_t strideA, int c, T *z, double *quad, int q,
                      void *stream) {
@@ -1075,6 +1120,12 @@ int plmc_potrf_ex_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t s
                       int *info, int with_inverse, int q, const double *eig_lo, void *stream) {
   (void)eig_lo;
   return plmc::potrf_impl<double, void>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, nullptr, stream);
+}
+int plmc_potrs_aug_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int64_t strideA, float *Vd, int q, void *stream) {
+  return plmc::potrs_aug_at<float>(A, n_pad, lda, naug, wcol0, strideA, Vd, q, stream);
+}
+int plmc_potrs_aug_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int64_t strideA, double *Vd, int q, void *stream) {
+  return plmc::potrs_aug_at<double>(A, n_pad, lda, naug, wcol0, strideA, Vd, q, stream);
 }
 int plmc_extract_col_f32(const float *A, int64_t n_pad, int64_t lda, int64_t strideA, int c, float *z, double *quad,
                          int q, void *stream) {

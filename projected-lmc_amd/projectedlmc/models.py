@@ -179,7 +179,40 @@ class ExactGP(torch.nn.Module):
             self.train_targets = fn(self.train_targets)
         return super()._apply(fn, *args, **kwargs)
 
+    # ---- eval-mode factorisation cache (gpytorch keeps its prediction strategy between calls; _engine.PosteriorCache)
+    def _prediction_cache(self):
+        c = self.__dict__.get("_pred_cache")
+        if c is None:
+            from . import _engine
+            c = self.__dict__["_pred_cache"] = _engine.PosteriorCache()
+        return c
+
+    def _drop_prediction_cache(self):
+        c = self.__dict__.get("_pred_cache")
+        if c is not None:
+            c.drop()
+
+    def train(self, mode=True):
+        if mode:
+            self._drop_prediction_cache()             # parameters are about to change: release the cached factor buffer
+        return super().train(mode)
+
+    def __deepcopy__(self, memo):
+        cache = self.__dict__.pop("_pred_cache", None)   # a copy starts without the (large) cached workspace
+        try:
+            import copy
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                new.__dict__[k] = copy.deepcopy(v, memo)
+            return new
+        finally:
+            if cache is not None:
+                self.__dict__["_pred_cache"] = cache
+
     def set_train_data(self, inputs=None, targets=None, strict=True):
+        self._drop_prediction_cache()
         if inputs is not None:
             if torch.is_tensor(inputs):
                 inputs = (inputs,)
@@ -268,7 +301,8 @@ class ExactGPModel(ExactGP):
             return self._wrap_posterior(mean + self.mean_module(x).reshape(self.n_tasks, -1), torch.diag_embed(v))
         mean, v = _engine.exact_posterior(lazy.kind, lazy.x1, lazy.ell.detach(),
                                           None if lazy.oscale is None else lazy.oscale.detach(),
-                                          noise.detach().to(lazy.ell.dtype), resid.detach(), xs, full_cov=full_cov)
+                                          noise.detach().to(lazy.ell.dtype), resid.detach(), xs, full_cov=full_cov,
+                                          cache=self._prediction_cache(), key=_engine.model_state_key(self, tx, self.train_targets))
         mean = mean + self.mean_module(x).reshape(self.n_tasks, -1)
         return self._wrap_posterior(mean, v if full_cov else torch.diag_embed(v))
 

@@ -296,7 +296,8 @@ class ProjectedGPModel(ExactGPModel):
             ell, noise, ytil = ell[ids], noise[ids], ytil[ids]
             osc = None if osc is None else osc[ids]
         return _engine.exact_posterior(lazy.kind, lazy.x1, ell, osc, noise, ytil, self.covar_module.select(x),
-                                       full_cov=full_cov)
+                                       full_cov=full_cov, cache=self._prediction_cache(),
+                                       key=_engine.model_state_key(self, tx, self.train_y) + (tuple(ids) if ids is not None else ()))
 
     def compute_loo(self, output=None):
         """LOO moments of the q latent GPs on the projected data, (n x q) each

@@ -1,0 +1,110 @@
+"""Eval-mode factorisation cache (VERDICT r2 missing item 3): the reference predicts through gpytorch's ExactGP.__call__
+(projected_lmc.py:1133-1134), whose prediction strategy keeps the factorisation across calls; experiments.py:316-331 calls
+the model batch by batch.  Here the first eval call runs the augmented sweep, later calls with unchanged parameters only
+forward-substitute the new cross-covariance columns (plmc_potrs_aug).  Parity: first call == second call == oracle;
+a parameter change, train() or set_train_data drops the cache."""
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(n=700, d=3, p=5, q=3, seed=0, dtype=torch.float64, **kw):
+    import projectedlmc as plmc
+    g = torch.Generator().manual_seed(seed)
+    X = 2 * torch.rand(n, d, generator=g, dtype=dtype) - 1
+    Y = torch.randn(n, p, generator=g, dtype=dtype)
+    torch.manual_seed(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = plmc.ProjectedGPModel(X, Y, p, q, mean_type=plmc.ZeroMean, kernel_type=plmc.MaternKernel, init_lmc_coeffs=True, **kw)
+    return m.to(dtype), X, Y
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, 2e-4)])
+def test_second_call_hits_the_cache_and_matches_first_call_and_oracle(dtype, tol):
+    from oracle import projected as oproj
+    from _bridge import oracle_params
+    m, X, Y = _model(dtype=dtype, BDN=False)
+    P = oracle_params(m)
+    g = torch.Generator().manual_seed(7)
+    Xs1 = 2 * torch.rand(300, 3, generator=g, dtype=dtype) - 1
+    Xs2 = 2 * torch.rand(211, 3, generator=g, dtype=dtype) - 1
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        o1 = m(Xs1.to(DEV))
+        c = m._prediction_cache()
+        assert (c.hits, c.misses) == (0, 1) and c.ws is not None and c.ws.with_inverse
+        o1b = m(Xs1.to(DEV))                       # same points again: forward substitution only
+        o2 = m(Xs2.to(DEV))                        # fewer points: fits the cached capacity
+        assert (c.hits, c.misses) == (2, 1)
+    mean1, cov1 = oproj.task_posterior(P, X.double(), Y.double(), Xs1.double())
+    mean2, cov2 = oproj.task_posterior(P, X.double(), Y.double(), Xs2.double())
+    var1, var2 = torch.diagonal(cov1).reshape(Xs1.shape[0], -1), torch.diagonal(cov2).reshape(Xs2.shape[0], -1)
+    for got, gotv, want, wantv in ((o1, o1.variance, mean1, var1), (o1b, o1b.variance, mean1, var1), (o2, o2.variance, mean2, var2)):
+        assert (got.mean.cpu().double() - want).abs().max() < tol * max(1.0, float(want.abs().max()))
+        assert (gotv.cpu().double() - wantv).abs().max() < tol * max(1.0, float(wantv.abs().max()))
+    # first and second call: the same factor, different routes for the augmented columns (inside the sweep -- fp32: on the split
+    # engine -- vs. the forward substitution on the MFMA of the element type): they agree far inside the oracle tolerance
+    agree = 1e-10 if dtype == torch.float64 else 5e-5
+    assert (o1.mean - o1b.mean).abs().max() < agree * max(1.0, float(o1.mean.abs().max()))
+    assert (o1.variance - o1b.variance).abs().max() < agree * max(1.0, float(o1.variance.abs().max()))
+
+
+def test_cache_is_dropped_when_the_model_changes():
+    from oracle import projected as oproj
+    from _bridge import oracle_params
+    m, X, Y = _model(dtype=torch.float64, BDN=True, scalar_B=True, diagonal_B=True)
+    g = torch.Generator().manual_seed(3)
+    Xs = 2 * torch.rand(150, 3, generator=g, dtype=torch.float64) - 1
+    m = m.to(DEV).eval()
+    c = m._prediction_cache()
+    with torch.no_grad():
+        m(Xs.to(DEV))
+        m(Xs.to(DEV))
+        assert (c.hits, c.misses) == (1, 1)
+        # (a) a parameter edited in place: new version -> miss, and the new posterior is the oracle's for the new parameters
+        m.covar_module.raw_lengthscale.add_(0.3)
+        out = m(Xs.to(DEV))
+        assert (c.hits, c.misses) == (1, 2)
+        mean, cov = oproj.task_posterior(oracle_params(m), X, Y, Xs)
+        var = torch.diagonal(cov).reshape(Xs.shape[0], -1)
+        assert (out.mean.cpu() - mean).abs().max() < 1e-8 * max(1.0, float(mean.abs().max()))
+        assert (out.variance.cpu() - var).abs().max() < 1e-8 * max(1.0, float(var.abs().max()))
+        # (b) more test points than the cached buffer holds: rebuilt with the larger capacity
+        Xl = 2 * torch.rand(400, 3, generator=g, dtype=torch.float64) - 1
+        m(Xl.to(DEV))
+        assert (c.hits, c.misses) == (1, 3) and c.ws.naug >= 401
+    # (c) train() releases the workspace; the next eval call starts over
+    m.train()
+    assert c.ws is None
+    m.eval()
+    with torch.no_grad():
+        m(Xs.to(DEV))
+    assert (c.hits, c.misses) == (1, 4)
+
+
+def test_exact_gp_model_uses_the_cache_too():
+    import projectedlmc as plmc
+    from oracle import gp_math as gm
+    g = torch.Generator().manual_seed(5)
+    n, d = 600, 4
+    X = 2 * torch.rand(n, d, generator=g, dtype=torch.float64) - 1
+    y = torch.randn(n, generator=g, dtype=torch.float64)
+    lik = plmc.GaussianLikelihood()
+    m = plmc.ExactGPModel(X, y, lik, mean_type=plmc.ZeroMean, kernel_type=plmc.RBFKernel).double().to(DEV).eval()
+    lik.eval()
+    Xs = (2 * torch.rand(128, d, generator=g, dtype=torch.float64) - 1).to(DEV)
+    with torch.no_grad():
+        a = m(Xs)
+        b = m(Xs)
+    c = m._prediction_cache()
+    assert (c.hits, c.misses) == (1, 1)
+    ell = m.covar_module.lengthscale.detach().reshape(1, d).cpu()
+    mu, cov = gm.exact_gp_posterior("rbf", X, ell, lik.noise.detach().reshape(1).cpu(), y.reshape(1, n), Xs.cpu(), None, 2.5)
+    for o in (a, b):
+        assert (o.mean.cpu().reshape(-1) - mu.reshape(-1)).abs().max() < 1e-8
+        assert (o.variance.cpu().reshape(-1) - torch.diagonal(cov, dim1=-2, dim2=-1).reshape(-1)).abs().max() < 1e-8

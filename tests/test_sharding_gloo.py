@@ -75,7 +75,7 @@ def _worker(rank, world, port, q, ret):
 
     # sharded PREDICTION (projected_lmc.py:1144,1152): every rank computes the posterior of its own latents, one
     # all-reduce of the (2, n*, p) partial mean / variance sums forms the task-space posterior on every rank
-    def fake_posterior(kind, X_, ell, oscale, noise, y, Xs_, full_cov=False):
+    def fake_posterior(kind, X_, ell, oscale, noise, y, Xs_, full_cov=False, cache=None, key=None):
         k, nu = kinds[kind]
         mu, cov = gm.exact_gp_posterior(k, X_, ell, noise, y, Xs_, oscale, nu)
         return mu, (cov if full_cov else torch.diagonal(cov, dim1=-2, dim2=-1))
