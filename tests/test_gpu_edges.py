@@ -159,22 +159,44 @@ def test_metric_shape_properties_fp32(eng):
 
 def test_sarcos_scale_single_latent_fp32(eng):
     """One rank's share of BASELINE config 5 (n = 44484, d = 21, one latent per GPU, Matern-5/2, fp32; 16 GB factor
-    buffer): the engine runs at that size (64-bit offsets, 348 block rows) and the outputs satisfy the linearity /
-    Euler identity of the Gaussian log-density: logp(y/2) - logp(y) = 3/8 * y.(Khat^-1 y)."""
+    buffer): the engine runs at that size (64-bit offsets, 348 block rows) and its outputs -- the d = 21 instance of the
+    fused K^-1 + gradient kernel included -- satisfy the identities that tie them together:
+      (1) linearity of the Gaussian log-density: logp(y/2) - logp(y) = 3/8 * y.(Khat^-1 y);
+      (2) scaling (Euler) identity of the gradient kernel: os dlogp/dos + s2 dlogp/ds2 = (quad - n) / 2;
+      (3) trace link with the LOO path: dlogp/ds2 = (alpha.alpha - tr Khat^-1) / 2, tr Khat^-1 = sum_i 1 / sigma2_loo_i;
+      (4) the 21 lengthscale gradients against a central difference of the log-density along the direction ell
+          (d/dc logp(c ell) at c = 1 = sum_k ell_k dlogp/dell_k)."""
     n, d, q = 44484, 21, 1
     g = torch.Generator().manual_seed(0)
     X = (2 * torch.rand(n, d, generator=g) - 1).to(DEV)
     y = torch.randn(q, n, generator=g).to(DEV)
-    ell = torch.full((q, d), 1.5, device=DEV)
+    ell = (1.2 + 0.6 * torch.rand(q, d, generator=g)).to(DEV)
     noise = torch.tensor([0.5], device=DEV)
-    yg = y.clone().requires_grad_()
-    lp = eng.exact_latent_log_prob("matern52", X, ell, None, noise, yg)
+    osc = torch.tensor([1.3], device=DEV)
+    yg, eg, ng, og = y.clone().requires_grad_(), ell.clone().requires_grad_(), noise.clone().requires_grad_(), osc.clone().requires_grad_()
+    lp = eng.exact_latent_log_prob("matern52", X, eg, og, ng, yg)
     lp.sum().backward()
-    assert bool(torch.isfinite(lp).all())
-    quad = -(yg.grad * y).sum(-1)
+    assert bool(torch.isfinite(lp).all()) and bool(torch.isfinite(eg.grad).all())
+    alpha = -yg.grad
+    quad = (alpha * y).sum(-1)
     assert bool((quad > 0).all())
-    lp_half = eng.exact_latent_log_prob("matern52", X, ell, None, noise, 0.5 * y)
+    # (1)
+    lp_half = eng.exact_latent_log_prob("matern52", X, ell, osc, noise, 0.5 * y)
     assert torch.allclose(lp_half - lp.detach(), 0.375 * quad, rtol=1e-4)
+    # (2)
+    lhs = osc * og.grad + noise * ng.grad
+    assert torch.allclose(lhs, 0.5 * (quad - n), rtol=2e-4, atol=5e-2), (lhs, 0.5 * (quad - n))
+    # (3)
+    s2, _ = eng.exact_loo("matern52", X, ell, osc, noise, y)
+    tr_kinv = (1.0 / s2.double()).sum(-1)
+    assert torch.allclose(ng.grad.double(), 0.5 * ((alpha.double() ** 2).sum(-1) - tr_kinv), rtol=2e-4, atol=5e-2)
+    # (4) fp32 log-densities of size ~1e5 carry ~1e-2 of rounding: a 2 % step keeps the difference well above it
+    h = 0.02
+    lp_p = eng.exact_latent_log_prob("matern52", X, ell * (1 + h), osc, noise, y)
+    lp_m = eng.exact_latent_log_prob("matern52", X, ell * (1 - h), osc, noise, y)
+    fd = (lp_p - lp_m).double() / (2 * h)
+    an = (ell.double() * eg.grad.double()).sum(-1)
+    assert torch.allclose(fd, an, rtol=2e-2, atol=1.0), (fd, an)
     eng.free_workspaces()
     torch.cuda.empty_cache()
 

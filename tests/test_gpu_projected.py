@@ -193,6 +193,62 @@ def test_latent_shards_sum_to_the_unsharded_step(plmc, q, world):
         assert torch.allclose(prm.grad, g, rtol=1e-8, atol=1e-11), (name, (prm.grad - g).abs().max())
 
 
+def test_sarcos_shaped_projected_model_p_equals_q(plmc):
+    """SURVEY.md 8e's reading of BASELINE config 5 at a size the dense fp64 oracle still handles: a ProjectedGPModel with as many
+    latents as tasks (p = q = 7: the p - q = 0 branches of projected_lmc.py:975-988, 1044-1047, 1210-1218), d = 21 inputs
+    (the d > 8 instance of the gradient kernels), n = 3000 (three groups of block rows: the look-ahead schedule and the
+    split engine), Matern-5/2.  Loss and every gradient against the oracle; the eval-mode posterior, and its per-rank
+    partial sums over 7 latent shards (what the all-reduce of the 7-GPU run adds up), against the oracle's posterior."""
+    n, d, p, q = 3000, 21, 7, 7
+    X, Y = _data(n, d, p, seed=17)
+    torch.manual_seed(3)
+    m = _model(plmc, X, Y, q, plmc.MaternKernel, init_lmc_coeffs=True, **VARIANTS["PLMC"])
+    m = perturb_(m.double(), scale=0.1)
+    P = oracle_params(m)
+    for k in pj.tensor_keys(P):
+        P[k].requires_grad_(True)
+    ref = -pj.projected_mll(P, X, Y)
+    ref.backward()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    Xd, Yd = X.to(DEV), Y.to(DEV)
+    m.train(); m.likelihood.train()
+    mll = plmc.ProjectedLMCmll(m.likelihood, m)
+    loss = -mll(m(Xd), Yd)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) < 1e-9 * abs(float(ref)), (float(loss), float(ref))
+    pm = param_map(m)
+    for pname, prm in m.named_parameters():
+        g_ref = P[pm[pname]].grad
+        assert prm.grad is not None, pname
+        assert torch.allclose(prm.grad.cpu(), g_ref, rtol=5e-6, atol=1e-8), (pname, (prm.grad.cpu() - g_ref).abs().max())
+    # eval-mode posterior, un-sharded and as the sum of the 7 ranks' shares
+    Xs = _data(257, d, p, seed=4)[0]
+    with torch.no_grad():
+        Pd = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in P.items()}
+        mean_ref, cov_ref = pj.task_posterior(Pd, X, Y, Xs)
+    var_ref = torch.diagonal(cov_ref).reshape(Xs.shape[0], p)
+    m.eval()
+    with torch.no_grad():
+        out = m(Xs.to(DEV))
+    assert (out.mean.cpu() - mean_ref).abs().max() < 1e-8 * max(1.0, float(mean_ref.abs().max()))
+    assert (out.variance.cpu() - var_ref).abs().max() < 1e-8 * max(1.0, float(var_ref.abs().max()))
+    from projectedlmc import _engine
+    mean_sum, var_sum = torch.zeros_like(mean_ref), torch.zeros_like(var_ref)
+    for rank in range(q):
+        torch.manual_seed(3)
+        ms = _model(plmc, X, Y, q, plmc.MaternKernel, init_lmc_coeffs=True, latent_shard=(rank, q), **VARIANTS["PLMC"]).double()
+        ms.load_state_dict(sd)
+        ms = ms.to(DEV).eval()
+        with torch.no_grad():
+            ml, vl = ms._latent_posterior(Xs.to(DEV))
+            mean_r, var_r = _engine.mix_posterior(ml, vl, ms.lmc_coefficients().detach()[ms.latent_ids], 0.0)
+        mean_sum += mean_r.cpu()
+        var_sum += var_r.cpu()
+    assert (mean_sum - mean_ref).abs().max() < 1e-8 * max(1.0, float(mean_ref.abs().max()))
+    assert (var_sum + m.eps - var_ref).abs().max() < 1e-8 * max(1.0, float(var_ref.abs().max()))
+
+
 def test_deferred_pivot_check_walks_the_same_jitter_ladder(plmc):
     """ProjectedLMCmll looks at the pivot check after the whole forward pass is queued and redoes the pass with jitter;
     the direct path (check inside the log-prob call) must land on the same jitter and the same loss."""
