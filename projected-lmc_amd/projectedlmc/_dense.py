@@ -21,14 +21,19 @@ def _load(ws, M, R):
     if ws.n_pad > m:
         idx = torch.arange(m, ws.n_pad, device=M.device)
         sq[:, idx, idx] = 1.0
-    L.call("plmc_write_rhs", ws.dtype, _hip.ptr(R.contiguous()), R.shape[1], m, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, ws.naug_pad,
+    Rc = R.contiguous()                  # (a transposed view makes a copy here: it must outlive the launch that reads it)
+    L.call("plmc_write_rhs", ws.dtype, _hip.ptr(Rc), R.shape[1], m, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, ws.naug_pad,
            q, _hip.stream_ptr(ws.device))
+    return Rc
 
 
 def _factor(ws, what):
     L = _hip.lib()
     L.call("plmc_potrf", ws.dtype, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.naug, ws.strideA, _hip.ptr(ws.Vd), _hip.ptr(ws.logdet),
            _hip.ptr(ws.info), int(ws.with_inverse), ws.q, _hip.stream_ptr(ws.device))
+    from . import settings
+    if not settings.check_cholesky.on():       # no pivot check wanted: no host sync either
+        return
     info = ws.info.cpu()
     if bool(info.any()):
         raise RuntimeError("%s: matrix not positive definite (first failing pivot per matrix: %s)" % (what, info.tolist()))
@@ -45,7 +50,7 @@ class SpdQuadLogdet(torch.autograd.Function):
         q, m = M.shape[0], M.shape[-1]
         need = any(ctx.needs_input_grad)
         ws = get_workspace(m, q, 1, dt, dev, True)
-        _load(ws, M.detach(), r.detach().reshape(q, 1, m))
+        keep = _load(ws, M.detach(), r.detach().reshape(q, 1, m))      # noqa: F841 (the copy lives until the sweep is queued)
         _factor(ws, "SpdQuadLogdet")
         st = _hip.stream_ptr(dev)
         L.call("plmc_extract_col", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, 0, _hip.ptr(ws.z), _hip.ptr(ws.quad), q, st)
@@ -75,7 +80,7 @@ def spd_half_solve(M, R):
     q, m, k = R.shape
     ws = get_workspace(m, q, k, dt, dev, False)
     with torch.no_grad():
-        _load(ws, M.detach(), R.detach().transpose(-1, -2))
+        keep = _load(ws, M.detach(), R.detach().transpose(-1, -2))      # noqa: F841 (the copy lives until the sweep is queued)
         _factor(ws, "spd_half_solve")
         return ws.A[:, :m, ws.n_pad:ws.n_pad + k].clone()
 

@@ -284,11 +284,9 @@ class ProjectedGPModel(ExactGPModel):
         lazy = self.covar_module(tx)
         ytil = self.project_data(self.train_y).detach()
         if hasattr(lazy, "log_prob_batch"):                    # SGPR latents (n_inducing_points)
-            if full_cov:
-                raise NotImplementedError("full_cov with inducing-point latents")
             with torch.no_grad():
                 noisy = lazy.add_noise(self.projected_noise().detach().to(lazy.ell.dtype))
-                return noisy.posterior(ytil, self.covar_module.select(x))
+                return noisy.posterior(ytil, self.covar_module.select(x), full_cov=full_cov)
         ids = self.latent_ids
         ell, osc, noise = lazy.ell.detach(), lazy.oscale, self.projected_noise().detach().to(lazy.ell.dtype)
         osc = None if osc is None else osc.detach()

@@ -95,8 +95,9 @@ class LazySgprKernel:
         self.owner._added_loss = -0.5 * (n * os_ - (A * A).sum((-2, -1))) / s1
         return -0.5 * (quad + logdet + n * math.log(2.0 * math.pi))
 
-    def posterior(self, y, xs):
-        """Predictive mean (q,ns) and variance (q,ns) of the SGPR posterior at xs."""
+    def posterior(self, y, xs, full_cov=False):
+        """Predictive mean (q,ns) and variance (q,ns) -- or, with full_cov, covariance (q,ns,ns) -- of the SGPR posterior at xs:
+        Q** - Q*n (Qnn + s2 I)^-1 Qn* = A*^T B^-1 A* = V*^T V* with B = I + A A^T / s2 = L_B L_B^T, V* = L_B^-1 A*."""
         A = self.interp()
         As = self.interp(xs)
         q, m, n = A.shape
@@ -105,5 +106,7 @@ class LazySgprKernel:
         sol = _dense.spd_half_solve(eye + (A @ A.transpose(-1, -2)) / s, torch.cat([A @ y.unsqueeze(-1), As], -1))
         c, Vs = sol[..., :1], sol[..., 1:]                                                # L_B^-1 [A y | A*]
         mean = (Vs.transpose(-1, -2) @ c).squeeze(-1) / s.reshape(q, 1)
+        if full_cov:
+            return mean, Vs.transpose(-1, -2) @ Vs
         var = (Vs * Vs).sum(-2)
         return mean, var

@@ -83,7 +83,18 @@ def test_projected_model_with_inducing_points():
     model.eval()
     with torch.no_grad():
         pred = model(X[:10].to(DEV))
+        full = model(X[:10].to(DEV), full_cov=True)                 # inducing-point latents with the full task covariance (:1149-1152)
     assert pred.mean.shape == (10, p) and bool((pred.variance > 0).all())
+    # oracle: latent SGPR posteriors mixed as :1143-1153
+    Z = sd["covar_module.inducing_points"].double().cpu()
+    mu_lat, cov_lat = osg.sgpr_posterior("matern", X, Z, pj.lengthscale(P), pj.projected_noise(P), ytil, X[:10])
+    Ht = pj.lmc_coefficients(P)
+    mean_ref = mu_lat.T @ Ht
+    cov_ref = sum(torch.kron(cov_lat[i], torch.outer(Ht[i], Ht[i])) for i in range(q)) + P["eps"] * torch.eye(10 * p, dtype=torch.float64)
+    assert torch.allclose(pred.mean.cpu(), mean_ref, rtol=1e-6, atol=1e-8)
+    assert torch.allclose(pred.variance.cpu(), torch.diagonal(cov_ref).reshape(10, p), rtol=1e-5, atol=1e-8)
+    assert torch.allclose(full.mean.cpu(), mean_ref, rtol=1e-6, atol=1e-8)
+    assert torch.allclose(full.lazy_covariance_matrix.evaluate().cpu(), cov_ref, rtol=1e-5, atol=1e-8)
 
 
 def oracle_params_like(model, sd):
