@@ -154,57 +154,63 @@ enum { SC_SU = 0, SC_SW = 1, SC_RU = 2, SC_RW = 3, SC_SA = 4, SC_RA = 5, SC_N = 
 // lambda_min is bounded below by the caller's `eig_lo` (the noise variance of a GP covariance) -- and by the smallest
 // diagonal entry, which brings in the identity padding of the rows beyond n (eigenvalue 1, whatever the noise).  SplitB3
 // needs no scales (all 1).  grid (q).
-constexpr int SCALE_NT = 1024;
+// Two launches: k_scale_scan (grid (SCAN_PARTS, q): largest / smallest diagonal entry and largest |augmented entry| of a slice
+// of the rows, into 3 SCAN_PARTS floats behind the scales) and k_split_scales (grid (q): reduction of the partials + the scales).
+constexpr int SCAN_PARTS = 32;
+__global__ __launch_bounds__(NTHREADS) void k_scale_scan(const float *__restrict__ A, int64_t n_pad, int64_t lda, int64_t strideA, int naug_pad,
+                                                         float *__restrict__ sc, int64_t sc_stride) {
+  __shared__ float r0[NTHREADS], r1[NTHREADS], r2[NTHREADS];
+  const int part = blockIdx.x, lat = blockIdx.y;
+  const int64_t rows = (n_pad + SCAN_PARTS - 1) / SCAN_PARTS, i0 = part * rows, i1 = i0 + rows < n_pad ? i0 + rows : n_pad;
+  float d = 0.0f, dm = 3.0e38f, am = 0.0f;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += NTHREADS) {
+    const float v = A[(int64_t)lat * strideA + i * lda + i];
+    d = fmaxf(d, v);
+    dm = fminf(dm, v);
+  }
+  // largest |entry| of the augmented columns: a maximum, unlike a sum, does not depend on the order -- the scales are the
+  // same in every run; sqrt(n_pad) times it bounds the 2-norm of every augmented column
+  const int cq = naug_pad / 4;                                        // 16-byte pieces per row
+  const int64_t items = (i1 > i0 ? i1 - i0 : 0) * cq;
+  const float *Aa = A + (int64_t)lat * strideA + i0 * lda + n_pad;
+#pragma unroll 8
+  for (int64_t w = threadIdx.x; w < items; w += NTHREADS) {
+    const float4 v = *reinterpret_cast<const float4 *>(Aa + (w / cq) * lda + (w % cq) * 4);
+    am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  r0[threadIdx.x] = d; r1[threadIdx.x] = dm; r2[threadIdx.x] = am;
+  __syncthreads();
+  for (int k = NTHREADS / 2; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) {
+      r0[threadIdx.x] = fmaxf(r0[threadIdx.x], r0[threadIdx.x + k]);
+      r1[threadIdx.x] = fminf(r1[threadIdx.x], r1[threadIdx.x + k]);
+      r2[threadIdx.x] = fmaxf(r2[threadIdx.x], r2[threadIdx.x + k]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float *o = sc + (int64_t)lat * sc_stride + SC_N + 3 * part;
+    o[0] = r0[0]; o[1] = r1[0]; o[2] = r2[0];
+  }
+}
 template <class S>
-__global__ __launch_bounds__(SCALE_NT) void k_split_scales(const float *__restrict__ A, int64_t n_pad, int64_t lda, int64_t strideA, int naug_pad,
-                                                           const float *__restrict__ eig_lo, float *__restrict__ sc, int64_t sc_stride) {
+__global__ __launch_bounds__(64) void k_split_scales(int64_t n_pad, const float *__restrict__ eig_lo, float *__restrict__ sc, int64_t sc_stride) {
   const int lat = blockIdx.x;
   float *o = sc + (int64_t)lat * sc_stride;
   if constexpr (S::NPL == 3) {
     if (threadIdx.x < SC_N) o[threadIdx.x] = 1.0f;
   } else {
-    __shared__ float red[SCALE_NT], redm[SCALE_NT];
-    float d = 0.0f, dm = 3.0e38f;
-    for (int64_t i = threadIdx.x; i < n_pad; i += SCALE_NT) {
-      const float v = A[(int64_t)lat * strideA + i * lda + i];
-      d = fmaxf(d, v);
-      dm = fminf(dm, v);
-    }
-    red[threadIdx.x] = d;
-    redm[threadIdx.x] = dm;
-    __syncthreads();
-    for (int k = SCALE_NT / 2; k > 0; k >>= 1) {
-      if ((int)threadIdx.x < k) {
-        red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + k]);
-        redm[threadIdx.x] = fminf(redm[threadIdx.x], redm[threadIdx.x + k]);
-      }
-      __syncthreads();
-    }
-    const float dmax = red[0], dmin = redm[0];
-    __syncthreads();
-    // largest |entry| of the augmented columns (whole 512-byte row pieces, 16 bytes per thread, 8 loads in flight); the bound of
-    // a column's 2-norm is sqrt(n_pad) times it -- a maximum, unlike a sum, does not depend on the order: the scales are
-    // the same in every run
-    float am = 0.0f;
-    const int cq = naug_pad / 4;                                      // 16-byte pieces per row
-    const int64_t items = (int64_t)n_pad * cq;
-    const float *Aa = A + (int64_t)lat * strideA + n_pad;
-#pragma unroll 8
-    for (int64_t w = threadIdx.x; w < items; w += SCALE_NT) {
-      const float4 v = *reinterpret_cast<const float4 *>(Aa + (w / cq) * lda + (w % cq) * 4);
-      am = fmaxf(fmaxf(am, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-    }
-    red[threadIdx.x] = am;
-    __syncthreads();
-    for (int k = SCALE_NT / 2; k > 0; k >>= 1) {
-      if ((int)threadIdx.x < k) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + k]);
-      __syncthreads();
-    }
     if (threadIdx.x == 0) {
+      float dmax = 0.0f, dmin = 3.0e38f, amax = 0.0f;
+      for (int p = 0; p < SCAN_PARTS; ++p) {
+        dmax = fmaxf(dmax, o[SC_N + 3 * p]);
+        dmin = fminf(dmin, o[SC_N + 3 * p + 1]);
+        amax = fmaxf(amax, o[SC_N + 3 * p + 2]);
+      }
       const float D = dmax > 0.0f ? dmax : 1.0f;
-      const float Rn = sqrtf((float)n_pad) * red[0] + 1e-30f;   // >= the 2-norm of every augmented column (zero right-hand side: any scale will do)
-      float lam = fminf(eig_lo[lat], dmin);                // (lambda_min <= every diagonal entry: still a lower bound)
-      if (!(lam > 1e-12f * D)) lam = 1e-12f * D;          // no usable bound: assume a condition number of 1e12
+      const float Rn = sqrtf((float)n_pad) * amax + 1e-30f;     // >= the 2-norm of every augmented column (zero right-hand side: any scale will do)
+      float lam = fminf(eig_lo[lat], dmin);                      // (lambda_min <= every diagonal entry: still a lower bound)
+      if (!(lam > 1e-12f * D)) lam = 1e-12f * D;                // no usable bound: assume a condition number of 1e12
       o[SC_SU] = b3_scale_for(sqrtf(D));
       o[SC_SW] = b3_scale_for(1.0f / sqrtf(lam));
       o[SC_RU] = b3_scale_for(D);
@@ -358,35 +364,77 @@ __global__ __launch_bounds__(NTHREADS) void k_gpanel_copy(T *A, int64_t lda, int
 }
 
 // Transpose of the group's inverse triangle: Vg[k][i] = Wg[i][k]^T for block pairs k <= i < G (Vg = Ugg^-1, upper,
-// K-major for the tile engine) and, when the inverse factor is wanted, the copy of Wg[i][k] into the factor buffer's
-// W columns (block row g0 + i, block column g0 + k).  grid (G (G + 1) / 2, q), 32 x 32 sub-tiles through LDS.
+// K-major for the tile engine); when the inverse factor is wanted, the copy of Wg[i][k] into the factor buffer's W columns
+// (block row g0 + i, block column g0 + k); and, for the split engine (S != void), Vg as k8-ordered planes with 128 GMAX columns
+// -- the A operand of k_gpanel_bf3 -- with zeros in the blocks below the diagonal (a macro row of the panel product runs both
+// of its block rows over the depth of the second).  One 128 x 128 block per workgroup, through an LDS tile: coalesced row
+// loads, coalesced transposed row stores, and the planes from 8 consecutive SOURCE columns per plane column.
 // (`Wg` with leading dimension lds_ and batch stride strideS: the group scratch in the sweep; the W columns of a finished
-// factor buffer in plmc_potrs_aug.)
-template <typename T>
+// factor buffer in plmc_potrs_aug.)  grid (planes ? GMAX * GMAX : G (G + 1) / 2, q).
+template <typename T, class S>
 __global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, int64_t lds_, int64_t strideS, int64_t strideG, T *__restrict__ Vg, int G,
-                                                     T *Wout, int64_t ldw, int64_t strideW) {
+                                                     T *Wout, int64_t ldw, int64_t strideW, unsigned short *__restrict__ VgP, int64_t vgp_lat_stride,
+                                                     const float *__restrict__ sc, int64_t sc_stride) {
   __builtin_amdgcn_s_setprio(3);
-  __shared__ T tile[32][33];
+  constexpr bool PLANES = !std::is_void<S>::value;
+  using SS = typename std::conditional<PLANES, S, SplitB3>::type;
+  using vec_t = typename Traits<T>::vec_t;
+  constexpr int EPV = Traits<T>::EPV, LT = NB + 1;
+  __shared__ T tile[NB * LT];
   const int lat = blockIdx.y;
-  int i = 0, k = (int)blockIdx.x;                    // blockIdx.x enumerates (i, k <= i) row by row
-  while (k > i) { k -= i + 1; ++i; }
+  int i, k;
+  if (PLANES) { k = (int)blockIdx.x / GMAX; i = (int)blockIdx.x % GMAX; }
+  else { i = 0; k = (int)blockIdx.x; while (k > i) { k -= i + 1; ++i; } }   // blockIdx.x enumerates (i, k <= i) row by row
+  if constexpr (PLANES) {
+    if (k > i || i >= G) {                                          // below the diagonal / beyond a short group: zero planes
+      unsigned short *P = VgP + (int64_t)lat * vgp_lat_stride + b3_index<SS>((int64_t)k * NB, 0, (int64_t)i * NB, GMAX * NB);
+      const b3_s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      constexpr int PER = SS::NPL * 128;
+      for (int w = threadIdx.x; w < 16 * PER; w += NTHREADS) {
+        const int k8 = w / PER, r = w % PER;
+        *reinterpret_cast<b3_s16x8 *>(P + ((int64_t)k8 * SS::NPL * GMAX * NB + (int64_t)(r / 128) * GMAX * NB + (r % 128)) * 8) = z;
+      }
+      return;
+    }
+  }
   const T *src = Wg + (int64_t)lat * strideS + (int64_t)i * NB * lds_ + (int64_t)k * NB;
   T *dst = Vg + (int64_t)lat * strideG + (int64_t)k * NB * LDG + (int64_t)i * NB;
   T *wo = Wout ? Wout + (int64_t)lat * strideW + (int64_t)i * NB * ldw + (int64_t)k * NB : nullptr;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
-  for (int bi = 0; bi < NB; bi += 32)
-    for (int bk = 0; bk < NB; bk += 32) {
+  constexpr int CPR = NB / EPV;                                       // 16-byte chunks per row
+  for (int c = threadIdx.x; c < NB * CPR; c += NTHREADS) {            // rows of Wg[i][k]: tile[row][col]
+    const int r = c / CPR, col = (c % CPR) * EPV;
+    const vec_t v = *reinterpret_cast<const vec_t *>(src + (int64_t)r * lds_ + col);
+    if (wo) *reinterpret_cast<vec_t *>(wo + (int64_t)r * ldw + col) = v;
 #pragma unroll
-      for (int r = 0; r < 32; r += 8) {
-        const T v = src[(int64_t)(bi + ty + r) * lds_ + bk + tx];
-        tile[ty + r][tx] = v;
-        if (wo) wo[(int64_t)(bi + ty + r) * ldw + bk + tx] = v;
+    for (int e = 0; e < EPV; ++e) tile[r * LT + col + e] = v[e];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < NB * CPR; c += NTHREADS) {            // rows of Vg[k][i]: dst[kk][ii] = tile[ii][kk]
+    const int kk = c / CPR, ii = (c % CPR) * EPV;
+    vec_t v;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) v[e] = tile[(ii + e) * LT + kk];
+    *reinterpret_cast<vec_t *>(dst + (int64_t)kk * LDG + ii) = v;
+  }
+  if constexpr (PLANES && sizeof(T) == 4) {
+    // plane element (kk, column ii) = tile[ii][kk]: 8 consecutive kk of one source row; thread = (k8 group, ii): 16 x 128 items
+    unsigned short *P = VgP + (int64_t)lat * vgp_lat_stride + b3_index<SS>((int64_t)k * NB, 0, (int64_t)i * NB, GMAX * NB);
+    const float scale = sc[(int64_t)lat * sc_stride + SC_SW];
+    for (int w = threadIdx.x; w < 16 * NB; w += NTHREADS) {
+      const int k8 = w / NB, ii = w % NB;
+      b3_s16x8 pl[SS::NPL];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        short o[SS::NPL];
+        SS::split((float)tile[ii * LT + k8 * 8 + r] * scale, o);
+#pragma unroll
+        for (int p = 0; p < SS::NPL; ++p) pl[p][r] = o[p];
       }
-      __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 32; r += 8) dst[(int64_t)(bk + ty + r) * LDG + bi + tx] = tile[tx][ty + r];
-      __syncthreads();
+      for (int p = 0; p < SS::NPL; ++p)
+        *reinterpret_cast<b3_s16x8 *>(P + ((int64_t)(k8 * SS::NPL + p) * GMAX * NB + ii) * 8) = pl[p];
     }
+  }
 }
 
 // PLMC_BF16X3 (fp32): the group's inverse triangle W[g0 + i][g0 + k] (k <= i < G, already in the factor buffer's W columns:
@@ -402,27 +450,6 @@ __global__ __launch_bounds__(NTHREADS) void k_wtri_planes(const float *__restric
   b3_split_block<S, false>(WA + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + (int64_t)(g0 + k) * NB, lda,
                            Pl + (int64_t)lat * pl_lat_stride + b3_index<S>((int64_t)i * NB, 0, wcol0 + (int64_t)(g0 + k) * NB, lda), lda,
                            sc[(int64_t)lat * sc_stride + SC_SW], nullptr, 0, threadIdx.x);
-}
-
-// PLMC_BF16X3 (fp32): Vgg = Ugg^-1 (upper, K-major, the group scratch k_vtrans wrote) as k8-ordered planes with 128 GMAX
-// columns, the A operand of k_gpanel_bf3.  Blocks below the diagonal (k > i) are written as zeros: a macro row of the
-// panel product runs both of its block rows over the depth of the second.  grid (GMAX * GMAX, q).
-template <class S>
-__global__ __launch_bounds__(NTHREADS) void k_vg_planes(const float *__restrict__ Vg, int64_t strideG, int G, unsigned short *__restrict__ VgP,
-                                                        int64_t vgp_lat_stride, const float *__restrict__ sc, int64_t sc_stride) {
-  const int lat = blockIdx.y, k = (int)blockIdx.x / GMAX, i = (int)blockIdx.x % GMAX;
-  unsigned short *P = VgP + (int64_t)lat * vgp_lat_stride + b3_index<S>((int64_t)k * NB, 0, (int64_t)i * NB, GMAX * NB);
-  if (k <= i && i < G) {
-    b3_split_block<S, false>(Vg + (int64_t)lat * strideG + (int64_t)k * NB * LDG + (int64_t)i * NB, LDG, P, GMAX * NB,
-                             sc[(int64_t)lat * sc_stride + SC_SW], nullptr, 0, threadIdx.x);
-  } else {
-    const b3_s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    constexpr int PER = S::NPL * 128;
-    for (int w = threadIdx.x; w < 16 * PER; w += NTHREADS) {              // (k8, plane, column) -> 16 zero bytes
-      const int k8 = w / PER, r = w % PER;
-      *reinterpret_cast<b3_s16x8 *>(P + ((int64_t)k8 * S::NPL * GMAX * NB + (int64_t)(r / 128) * GMAX * NB + (r % 128)) * 8) = z;
-    }
-  }
 }
 
 // PLMC_BF16X3 (fp32): rows of the factor buffer as planes of `Praw` -- the raw (not yet solved) rows of the FIRST group, which
@@ -447,7 +474,7 @@ __global__ __launch_bounds__(NTHREADS) void k_raw_planes(const float *__restrict
 }
 
 // PLMC_BF16X3 (fp32): the group panel on the bf16 matrix cores.  P[i] = sum_{k <= i} Vgg[k][i]^T A[k] for the block rows
-// i of the group and one 128-column strip t of the column map, from the planes of Vgg (VgP, k_vg_planes) and of the raw
+// i of the group and one 128-column strip t of the column map, from the planes of Vgg (VgP, k_vtrans) and of the raw
 // rows (Praw: k_update_bf3 of the previous group / k_raw_planes).  The operands are read from plane buffers only, so the
 // result goes IN PLACE into the factor buffer -- no panel buffer, no copy kernel -- and, while the tile is in LDS, as planes
 // into the rolling buffer `Pl` for the trailing updates.  A workgroup takes the macro rows (2 a, 2 a + 1) at the depth of
@@ -829,7 +856,11 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   hipLaunchKernelGGL(k_zero_diag_out<T>, dim3(m > GMAX ? m : GMAX, q), dim3(NTHREADS), 0, st, Vd, strideV, m, Wg, (int64_t)LDG,
                      strideV, (int64_t)NB * LDG + NB, GMAX);
   if constexpr (bf3)                                      // scales of the operand families (SplitB3: ones), before anything splits
-    hipLaunchKernelGGL((k_split_scales<SS>), dim3(q), dim3(SCALE_NT), 0, st, (const float *)A, n_pad, lda, strideA, (int)naug_pad, eig_lo, scl, sc_lat);
+  {
+    if (SS::NPL == 2)
+      hipLaunchKernelGGL(k_scale_scan, dim3(SCAN_PARTS, q), dim3(NTHREADS), 0, st, (const float *)A, n_pad, lda, strideA, (int)naug_pad, scl, sc_lat);
+    hipLaunchKernelGGL((k_split_scales<SS>), dim3(q), dim3(64), 0, st, n_pad, eig_lo, scl, sc_lat);
+  }
   auto finish = [&]() {
     hipLaunchKernelGGL(k_logdet<T>, dim3(q), dim3(NTHREADS), 0, st, (const T *)A, n_pad, lda, strideA, logdet, info);
     return launch_status("potrf_impl");
@@ -874,8 +905,9 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   auto vtrans = [&](int gi, hipStream_t s) {
     const int g0 = G0(gi), G = G0(gi + 1) - g0;
     T *wo = WA ? WA + (int64_t)g0 * NB * lda + (int64_t)g0 * NB : (T *)nullptr;
-    hipLaunchKernelGGL((k_vtrans<T>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)Wg, (int64_t)LDG, strideV, strideV, Vg2[gi & 1], G, wo,
-                       lda, strideA);
+    // (split engine: also the planes of Vgg, zero blocks included -- one workgroup per block of the GMAX x GMAX grid)
+    hipLaunchKernelGGL((k_vtrans<T, S>), dim3(bf3 ? GMAX * GMAX : G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)Wg, (int64_t)LDG, strideV,
+                       strideV, Vg2[gi & 1], G, wo, lda, strideA, VgP, pl_lat, (const float *)scl, sc_lat);
   };
   // PLMC_BF16X3: planes of the group's inverse triangle (read back from the W columns k_vtrans wrote; any stream behind it)
   auto wtri_planes = [&](int gi, hipStream_t s) {
@@ -885,12 +917,6 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       hipLaunchKernelGGL((k_wtri_planes<SS>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const float *)WA, lda, strideA, g0, planes(g0), pl_lat,
                          wcol0, (const float *)scl, sc_lat);
     }
-  };
-  // PLMC_BF16X3: planes of Vgg for the group panel (behind k_vtrans; same stream as the panel that reads them)
-  auto vg_planes = [&](int gi, hipStream_t s) {
-    if constexpr (bf3)
-      hipLaunchKernelGGL((k_vg_planes<SS>), dim3(GMAX * GMAX, q), dim3(NTHREADS), 0, s, (const float *)Vg2[gi & 1], strideV, G0(gi + 1) - G0(gi), VgP,
-                         pl_lat, (const float *)scl, sc_lat);
   };
   // PLMC_BF16X3: planes of the first group's raw rows (columns of the bulk panel: everything right of the second group + aug)
   auto raw_planes0 = [&](hipStream_t s, int u0) {
@@ -921,8 +947,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // onto four hardware queues; with the gradient stream of the Python layer this library already uses four) and
   // serialised the chain behind bulk launches: sweep + accumulation took exactly the sum of the two.
   hipEvent_t e_entry = sync_event(0), e_v = sync_event(1), e_gh = sync_event(2), e_p = sync_event(3), e_hd = sync_event(4),
-             e_tail = sync_event(5), e_doneC = sync_event(6), e_doneH = sync_event(7), e_doneK = sync_event(8);
-  const bool la = C && H && e_entry && e_v && e_gh && e_p && e_hd && e_tail && e_doneC && e_doneH && e_doneK && ng > 2;
+             e_tail = sync_event(5), e_doneC = sync_event(6), e_doneH = sync_event(7), e_prev = sync_event(8);
+  const bool la = C && H && e_entry && e_v && e_gh && e_p && e_hd && e_tail && e_doneC && e_doneH && e_prev && ng > 2;
   if (!la) {
     // one stream: chain -> transpose -> group panel over every column -> trailing update of every row below
     // PLMC_BF16X3: which engine a tile goes through must not depend on the schedule -- as under the look-ahead, the panel
@@ -933,7 +959,6 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       chain(gi, st);
       vtrans(gi, st);
       wtri_planes(gi, st);
-      vg_planes(gi, st);
       if (bf3) {
         const int g2 = G0(gi + 2);
         gpanel(g0, g1 - g0, cm_buf(g1, g2 - g1, 0, 0, 0), Vg2[gi & 1], st, 1);
@@ -964,6 +989,18 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // gpanel_rest(gi) read: by then C has waited for e_hd(gi), recorded behind it.  U1 / head / tail touch disjoint
   // tiles; every tile receives its updates in the same order as on one stream, so the result is bit-identical to the
   // serial schedule (tests/test_gpu_edges.py).
+  // The helper streams, the ordering events and the group scratch are per DEVICE: a second sweep on this device from ANOTHER
+  // caller stream must not start while the previous one is in flight (same caller stream: stream order does it).
+  {
+    int dev = 0;
+    static hipStream_t last_caller[64] = {nullptr};
+    static bool have_prev[64] = {false};
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+      if (have_prev[dev] && last_caller[dev] != st) (void)hipStreamWaitEvent(st, e_prev, 0);
+      last_caller[dev] = st;
+      have_prev[dev] = true;
+    }
+  }
   (void)hipEventRecord(e_entry, st);
   (void)hipStreamWaitEvent(C, e_entry, 0);
   (void)hipStreamWaitEvent(H, e_entry, 0);
@@ -974,7 +1011,6 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     const T *Vg = Vg2[gi & 1];
     chain(gi, C);
     vtrans(gi, C);
-    vg_planes(gi, C);                                                           // planes of Vgg: both panels read them
     (void)hipEventRecord(e_v, C);
     if (gi > 0 || bf3) (void)hipStreamWaitEvent(C, e_hd, 0);                   // head(gi - 1): rows R0 final (split engine: and their raw planes)
     gpanel(g0, G, cm_buf(g1, g2 - g1, 0, 0, 0), Vg, C, 1);                      // head columns R1
@@ -1001,6 +1037,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   (void)hipEventRecord(e_doneH, H);
   (void)hipStreamWaitEvent(st, e_doneC, 0);
   (void)hipStreamWaitEvent(st, e_doneH, 0);
+  (void)hipEventRecord(e_prev, st);                      // everything of this sweep is behind this point of the caller's stream
 
   return finish();
 }
@@ -1029,8 +1066,8 @@ int potrs_aug_at(T *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int6
   const ColMap<T> cm{0, 0, Tu, 0, 0, n_pad, (T *)nullptr, lda, strideA};
   for (int g0 = 0; g0 < m; g0 += GMAX) {
     const int g1 = g0 + GMAX < m ? g0 + GMAX : m, G = g1 - g0;
-    hipLaunchKernelGGL((k_vtrans<T>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, st, (const T *)(WA + (int64_t)g0 * NB * lda + (int64_t)g0 * NB), lda,
-                       strideA, strideV, Vg, G, (T *)nullptr, lda, strideA);
+    hipLaunchKernelGGL((k_vtrans<T, void>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, st, (const T *)(WA + (int64_t)g0 * NB * lda + (int64_t)g0 * NB), lda,
+                       strideA, strideV, Vg, G, (T *)nullptr, lda, strideA, (unsigned short *)nullptr, (int64_t)0, (const float *)nullptr, (int64_t)0);
     {
       const double prods = G * (G + 1) / 2.0;
       ProfScope ps(PK_GPANEL, st, q * (double)Tu * prods * 2.0 * nb3, q * (double)Tu * (prods + G) * nb * nb * esz);
