@@ -70,8 +70,9 @@ class WhitenedInterp(torch.autograd.Function):
         L.call("plmc_write_rhs", dt, None, 0, m, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, ws.naug_pad, q, st)
         L.call("plmc_assemble_cross", dt, k, _hip.ptr(Zc), m, _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc),
                _hip.ptr(ws.A), ws.lda, ws.strideA, ws.n_pad, ws.n_pad, q, st)
-        L.call("plmc_potrf", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, n, ws.strideA, _hip.ptr(ws.Vd),
-               _hip.ptr(ws.logdet), _hip.ptr(ws.info), int(need_grad), q, st)
+        # eig_lo = the jitter: lambda_min(K_ZZ + jitter I) >= jitter (bound for the fp16 split of the bulk fp32 products)
+        L.call("plmc_potrf_ex", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, n, ws.strideA, _hip.ptr(ws.Vd),
+               _hip.ptr(ws.logdet), _hip.ptr(ws.info), int(need_grad), q, _hip.ptr(jit), st)
         info = ws.info.cpu()
         if bool(info.any()):
             raise RuntimeError("K_ZZ + jitter not positive definite (first failing pivot per latent: %s)" % info.tolist())
@@ -142,8 +143,8 @@ class GaussianKLToKernelPrior(torch.autograd.Function):
         L.call("plmc_assemble", dt, _hip.KIND[kind], _hip.ptr(Zc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(jit),
                _hip.ptr(ws.A), ws.lda, ws.strideA, q, st)
         L.call("plmc_write_rhs", dt, _hip.ptr(rhs_t), n + 1, n, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, ws.naug_pad, q, st)
-        L.call("plmc_potrf", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, n + 1, ws.strideA, _hip.ptr(ws.Vd),
-               _hip.ptr(ws.logdet), _hip.ptr(ws.info), 1, q, st)
+        L.call("plmc_potrf_ex", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, n + 1, ws.strideA, _hip.ptr(ws.Vd),
+               _hip.ptr(ws.logdet), _hip.ptr(ws.info), 1, q, _hip.ptr(jit), st)
         info = ws.info.cpu()
         if bool(info.any()):
             raise RuntimeError("K_ZZ + jitter not positive definite (first failing pivot per latent: %s)" % info.tolist())
@@ -191,8 +192,8 @@ def prior_cholesky(kind, Z, ell, oscale, jitter):
     jit = torch.full((q,), float(jitter), dtype=dt, device=dev)
     L.call("plmc_assemble", dt, _hip.KIND[kind], _hip.ptr(Zc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(jit),
            _hip.ptr(ws.A), ws.lda, ws.strideA, q, st)
-    L.call("plmc_potrf", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, 0, ws.strideA, _hip.ptr(ws.Vd), _hip.ptr(ws.logdet),
-           _hip.ptr(ws.info), 0, q, st)
+    L.call("plmc_potrf_ex", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, 0, ws.strideA, _hip.ptr(ws.Vd), _hip.ptr(ws.logdet),
+           _hip.ptr(ws.info), 0, q, _hip.ptr(jit), st)
     if bool(ws.info.cpu().any()):
         raise RuntimeError("K_ZZ + jitter not positive definite")
     return torch.triu(ws.A[:, :n, :n]).transpose(-1, -2).contiguous()
@@ -216,8 +217,8 @@ def unwhitened_predictive(kind, Z, X, ell, oscale, mvar, Ls, jitter):
     L.call("plmc_write_rhs", dt, None, 0, n, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, ws.naug_pad, q, st)
     L.call("plmc_assemble_cross", dt, k, _hip.ptr(Zc), n, _hip.ptr(Xc), ns, d, _hip.ptr(ellc), _hip.ptr(osc),
            _hip.ptr(ws.A), ws.lda, ws.strideA, ws.n_pad, ws.n_pad, q, st)
-    L.call("plmc_potrf", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ns, ws.strideA, _hip.ptr(ws.Vd), _hip.ptr(ws.logdet),
-           _hip.ptr(ws.info), 1, q, st)
+    L.call("plmc_potrf_ex", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ns, ws.strideA, _hip.ptr(ws.Vd), _hip.ptr(ws.logdet),
+           _hip.ptr(ws.info), 1, q, _hip.ptr(jit), st)
     if bool(ws.info.cpu().any()):
         raise RuntimeError("K_ZZ + jitter not positive definite")
     C = ws.A[:, :n, ws.n_pad:ws.n_pad + ns]                                          # U^-T K_ZX
