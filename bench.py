@@ -414,7 +414,7 @@ def main():
             # HBM bytes per launch from the PMC counters.  They cannot be read from inside the process: they come from
             # rocprofv3 --pmc passes of this same command -- the committed ones if they were measured on THIS build
             # (build key over the library sources), else (--pmc) two child runs now, else null.
-            sname = {2: "plmc::SplitH2", 3: "plmc::SplitB3"}.get(split)
+            sname = {2: "SplitH2", 3: "SplitB3"}.get(split)      # as tools/pmc_aggregate.py writes the names (plmc:: stripped)
             kname = ({"k_trail": "k_update_bf3<%s, 0>" % sname, "k_trail_head": "k_update_bf3<%s, 3>" % sname,
                       "k_kinv_grad": "k_kinv_grad_bf3<%s, 8, false>" % sname} if split else
                      {"k_trail": "k_update<float, 0, 4>", "k_trail_head": "k_update<float, 3, 4>",

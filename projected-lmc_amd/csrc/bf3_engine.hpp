@@ -132,9 +132,15 @@ __device__ __forceinline__ void b3_split_block(const float *__restrict__ Sp, int
 //   Bp: likewise, first of the 128 B columns, ldb_ columns;  K % 64 == 0;  lds: b3_lds_bytes<S>(), 16-byte aligned, the
 //   kernel's ONLY __shared__ object (a second one makes hipcc drain the DMA before every fragment read).
 // All 512 threads must call it; ends with a barrier (LDS free for the epilogue).
-template <class S>
+// `pre` (optional): called once, right behind the LAST DMA issue of the loop, two stages before its end -- the place for the
+// epilogue's first C loads (b3_preload): NPRE = the vector-memory loads it issues (0 or 8).  They are the youngest memory
+// operations of the wave, so the remaining barriers wait for "all but the NPRE youngest" and the loads stay in flight
+// through the last two stages (an older load would hold back every DMA piece behind it: vmcnt counts in issue order).
+struct B3NoPre { __device__ __forceinline__ void operator()() const {} };
+template <class S, int NSTG = 2, int NPRE = 0, class PRE = B3NoPre>
 __device__ __forceinline__ void b3_mainloop(Acc<float> &acc0, Acc<float> &acc1, const unsigned short *__restrict__ Ap, int64_t lda_,
-                                            const unsigned short *__restrict__ Bp, int64_t ldb_, int K, unsigned char *lds) {
+                                            const unsigned short *__restrict__ Bp, int64_t ldb_, int K, unsigned char *lds, PRE pre = PRE()) {
+  static_assert(NPRE == 0 || (NPRE == 8 && NSTG == 2), "pre-loads: eight, two-stage loop only");
   constexpr int NPL = S::NPL, STAGE = b3_stage_bytes<S>();
   typedef typename S::frag_t frag_t;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -214,15 +220,53 @@ __device__ __forceinline__ void b3_mainloop(Acc<float> &acc0, Acc<float> &acc1, 
     }
   };
   const int nst = K / B3_K;                                        // even
-  issue(0);
+  if constexpr (NSTG == 2) {
+    issue(0);
 #pragma unroll 1
-  for (int s = 0; s < nst; s += 2) {
-    __syncthreads();               // (vmcnt(0) + barrier) stage s has landed for every wave; stage s - 1 is read out
-    issue(1);                      // nst is even: stage s + 1 always exists
+    for (int s = 0; s + 2 < nst; s += 2) {
+      __syncthreads();               // (vmcnt(0) + barrier) stage s has landed for every wave; stage s - 1 is read out
+      issue(1);                      // nst is even: stage s + 1 always exists
+      compute(0);
+      __syncthreads();
+      issue(0);
+      compute(1);
+    }
+    __syncthreads();                 // the last two stages
+    issue(1);
+    pre();
     compute(0);
-    __syncthreads();
-    if (s + 2 < nst) issue(0);
-    compute(1);
+    if constexpr (NPRE == 0) {
+      __syncthreads();
+      compute(1);
+    } else {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // the last stage has landed; the pre-loads may still fly
+      __builtin_amdgcn_s_barrier();
+      compute(1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                // LDS free for the epilogue (no vmcnt wait)
+      return;
+    }
+  } else {
+    // three stages: the DMA of stage s + 2 is issued behind the barrier that ends the reads of stage s - 1, so a stage has
+    // two stage times to land (fabric / HBM latency under load is longer than one); before stage s is read only ITS pieces
+    // must have landed: the 3 NPL younger ones of stage s + 1 may stay in flight (vmcnt counts in issue order)
+    static_assert(NSTG == 3 && 3 * STAGE <= 160 * 1024, "three stages must fit the LDS");
+    issue(0);
+    issue(1);
+    int buf = 0;
+#pragma unroll 1
+    for (int s = 0; s < nst; ++s) {
+      if (s + 1 < nst) {
+        if constexpr (NPL == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (s + 2 < nst) issue(buf == 0 ? 2 : buf - 1);               // (s + 2) % 3 = the buffer of stage s - 1
+      compute(buf);
+      buf = buf == 2 ? 0 : buf + 1;
+    }
   }
   __syncthreads();
 }
@@ -238,54 +282,69 @@ template <class S> __device__ __forceinline__ void b3_combine(Acc<float> &acc0, 
     }
 }
 
-// Epilogue of one 128 x 128 half of the macro tile: tile_writeback (gemm_core.hpp) for fp32 plus, with PLANES, the FINAL
-// values of the tile (times `pscale`) also as k8-ordered planes -- the next consumer's operand, written while the tile is
-// still in LDS instead of by a separate split pass.  `Pp` = plane buffer at (k = the tile's first row, plane 0, the tile's
-// first column), `pld` its columns.  Per 64-row pass the finals go back into the staging area (for the read-modify-write
-// modes), then every thread splits 8 rows x 4 columns.  tid = threadIdx.x & 255; `live` as in tile_writeback;
-// `planes_live`: this half also writes planes (both wave-uniform per half).
-template <class S, int MODE, bool PLANES>
+// Epilogue of one 128 x 128 half of the macro tile (tid = threadIdx.x & 255): the tile goes through the half's staging area
+// in two passes of 64 rows (pass h staged by the wave row wm == h) and leaves as 16-byte row chunks, 8 per thread and pass
+// (the layout of tile_writeback<float>, gemm_core.hpp).  One workgroup per CU means nothing else covers the latency of the C
+// loads of the read-modify-write modes, so ALL 16 chunks of a thread are in flight at once: those of pass 0 from
+// b3_preload (issued inside the main loop, PRE) or at entry, those of pass 1 at entry (tile_writeback keeps two in flight:
+// 8 dependent round trips per tile, 9 us of the 55 a depth-1024 tile took; tools/engine_rate_probe.hip).
+// With PLANES the FINAL values (times `pscale`) are also written as k8-ordered planes -- the next consumer's operand, while
+// the tile is still in LDS instead of by a separate split pass: `Pp` = plane buffer at (k = the tile's first row, plane 0,
+// the tile's first column), `pld` its columns; per pass the finals go back into the staging area, then every thread splits
+// 8 rows x 4 columns.  `live`: a half without a tile takes part in the barriers only (its descriptor has zero records: loads
+// give 0, stores are dropped); `planes_live`: this half also writes planes (both wave-uniform per half).
+constexpr int B3_WB_NCH = 8;
+__device__ __forceinline__ void b3_preload(f32x4 (&vc)[B3_WB_NCH], const float *Cg, int64_t ldc, int tid, bool live) {
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Cg), 0, __builtin_amdgcn_readfirstlane(live ? 0x7fffffff : 0), 0x00020000);
+  const unsigned voff = (unsigned)(((int64_t)(tid / 32) * ldc + (tid % 32) * 4) * 4);
+  const unsigned rstep = (unsigned)((int64_t)8 * ldc * 4);
+#pragma unroll
+  for (int h = 0; h < B3_WB_NCH; ++h) vc[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rC, voff, (unsigned)h * rstep, 0));
+}
+template <class S, int MODE, bool PLANES, bool PRE = false>
 __device__ __forceinline__ void b3_writeback(const Acc<float> &acc, float *Cg, int64_t ldc, float *smem, int tid, bool live,
-                                             unsigned short *Pp = nullptr, int64_t pld = 0, bool planes_live = true, float pscale = 1.0f) {
-  if constexpr (!PLANES) {
-    tile_writeback<float, MODE>(acc, Cg, ldc, smem, tid, live);
-  } else {
-    constexpr bool ADD = MODE == WB_ADD || MODE == WB_SUB;
-    typedef int i32x4_t __attribute__((ext_vector_type(4)));
-    constexpr int LDW = 132, CPR = 32, NCH = 8, RSTEP = 8;       // as tile_writeback<float>: 16-byte chunks, 8 per thread and pass
-    const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int row0 = tid / CPR, col0 = (tid % CPR) * 4;
-    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(Cg, 0, __builtin_amdgcn_readfirstlane(live ? 0x7fffffff : 0), 0x00020000);
-    const unsigned voff = (unsigned)(((int64_t)row0 * ldc + col0) * 4);
-    const unsigned rstep = (unsigned)((int64_t)RSTEP * ldc * 4);
-    f32x4 vc[NCH];
+                                             unsigned short *Pp = nullptr, int64_t pld = 0, bool planes_live = true, float pscale = 1.0f,
+                                             const f32x4 *vc0 = nullptr) {
+  constexpr bool ADD = MODE == WB_ADD || MODE == WB_SUB;
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
+  constexpr int LDW = 132, CPR = 32, NCH = B3_WB_NCH, RSTEP = 8;
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int row0 = tid / CPR, col0 = (tid % CPR) * 4;
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(Cg, 0, __builtin_amdgcn_readfirstlane(live ? 0x7fffffff : 0), 0x00020000);
+  const unsigned voff = (unsigned)(((int64_t)row0 * ldc + col0) * 4);
+  const unsigned rstep = (unsigned)((int64_t)RSTEP * ldc * 4);
+  f32x4 vc[2][NCH];
+  if (ADD) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if (ADD) {                                                   // the C rows of this pass, all in flight while the pass is staged
+    for (int h = 0; h < NCH; ++h)
+      vc[0][h] = PRE ? vc0[h] : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rC, voff, (unsigned)h * rstep, 0));
 #pragma unroll
-        for (int h = 0; h < NCH; ++h)
-          vc[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rC, voff, (unsigned)(half * 8 + h) * rstep, 0));
-      }
-      if (half) __syncthreads();                                   // plane pass of the previous half is done with the staging area
-      if (wm == half) {
+    for (int h = 0; h < NCH; ++h) vc[1][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rC, voff, (unsigned)(8 + h) * rstep, 0));
+  }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();                                   // the previous pass is done with the staging area
+    if (wm == half) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = mt * 16 + Traits<float>::acc_row(lane, r);
+      for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) smem[row * LDW + wn * 64 + nt * 16 + (lane & 15)] = acc.v[mt][nt][r];
-          }
-      }
-      __syncthreads();
+        for (int r = 0; r < 4; ++r) {
+          const int row = mt * 16 + Traits<float>::acc_row(lane, r);
 #pragma unroll
-      for (int h = 0; h < NCH; ++h) {
-        float *sp = smem + (row0 + h * RSTEP) * LDW + col0;
-        const f32x4 sv = *reinterpret_cast<const f32x4 *>(sp);
-        const f32x4 o = MODE == WB_ADD ? vc[h] + sv : (MODE == WB_SUB ? vc[h] - sv : (MODE == WB_STORE_NEG ? -sv : sv));
-        if (MODE != WB_STORE) *reinterpret_cast<f32x4 *>(sp) = o;  // each thread owns its chunks: the staging area now holds the finals
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o), rC, voff + (unsigned)(half * 8 + h) * rstep, 0, 0);
-      }
+          for (int nt = 0; nt < 4; ++nt) smem[row * LDW + wn * 64 + nt * 16 + (lane & 15)] = acc.v[mt][nt][r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      float *sp = smem + (row0 + h * RSTEP) * LDW + col0;
+      const f32x4 sv = *reinterpret_cast<const f32x4 *>(sp);
+      const f32x4 o = MODE == WB_ADD ? vc[half][h] + sv : (MODE == WB_SUB ? vc[half][h] - sv : (MODE == WB_STORE_NEG ? -sv : sv));
+      if (PLANES && MODE != WB_STORE) *reinterpret_cast<f32x4 *>(sp) = o;   // each thread owns its chunks: the staging area now holds the finals
+      // row-chunk offset in voffset, soffset = 0: the store-data hazard note of gemm_core.hpp
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o), rC, voff + (unsigned)(half * 8 + h) * rstep, 0, 0);
+    }
+    if constexpr (PLANES) {
       __syncthreads();
       if (live && planes_live) {                                   // 64 rows = 8 k8 groups x 32 column quads: one item per thread
         const int k8 = tid >> 5, c4 = (tid & 31) * 4;

@@ -270,22 +270,25 @@ __global__ __launch_bounds__(B3_NT, 2) void k_update_bf3(float *A, int64_t lda, 
   acc0.zero();
   acc1.zero();
   const unsigned short *Pr = Pl + (int64_t)lat * pl_lat_stride + b3_index<S>(kr0 - r_lo * NB, 0, 0, lda);
-  b3_mainloop<S>(acc0, acc1, Pr + (int64_t)ibm * NB * 8, lda, Pr + colp * 8, lda, depth, lds);
-  b3_combine<S>(acc0, acc1, 1.0f / (scl[SC_SU] * sB));
   const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
   float *C = Cb + (int64_t)(ibm + half) * NB * ldc + col0;
   float *stg = reinterpret_cast<float *>(lds + half * B3_WB_BYTES);
   const bool live = half ? v1 : v0;
   const int tid = (int)threadIdx.x & 255;
+  // the C rows of the first write-back pass are requested two stages before the main loop ends (nothing for a first touch)
+  f32x4 vc0[B3_WB_NCH];
+  auto pre = [&]() { b3_preload(vc0, C, ldc, tid, live && !first); };
+  b3_mainloop<S, 2, B3_WB_NCH>(acc0, acc1, Pr + (int64_t)ibm * NB * 8, lda, Pr + colp * 8, lda, depth, lds, pre);
+  b3_combine<S>(acc0, acc1, 1.0f / (scl[SC_SU] * sB));
   if (Praw && ibm < raw_end) {              // uniform per workgroup; a half at or beyond raw_end writes no planes
     unsigned short *Pp = Praw + (int64_t)lat * praw_lat_stride + b3_index<S>((int64_t)(ibm + half - ib0) * NB, 0, colp, lda);
     const bool pl = ibm + half < raw_end;
     if (first) b3_writeback<S, WB_STORE_NEG, true>(acc0, C, ldc, stg, tid, live, Pp, lda, pl, sRaw);
-    else b3_writeback<S, WB_SUB, true>(acc0, C, ldc, stg, tid, live, Pp, lda, pl, sRaw);
+    else b3_writeback<S, WB_SUB, true, true>(acc0, C, ldc, stg, tid, live, Pp, lda, pl, sRaw, vc0);
     return;
   }
-  if (first) tile_writeback<float, WB_STORE_NEG>(acc0, C, ldc, stg, tid, live);   // first touch of a W tile
-  else tile_writeback<float, WB_SUB>(acc0, C, ldc, stg, tid, live);
+  if (first) b3_writeback<S, WB_STORE_NEG, false>(acc0, C, ldc, stg, tid, live);   // first touch of a W tile
+  else b3_writeback<S, WB_SUB, false, true>(acc0, C, ldc, stg, tid, live, nullptr, 0, true, 1.0f, vc0);
 }
 
 // Group panel: U^-T applied to the whole block row of the group as products with Vgg = Ugg^-1 (upper, K-major, leading
@@ -554,6 +557,40 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_kacc(T *A, int6
   else { C = A + (int64_t)lat * strideA + (int64_t)jb * NB * lda + (int64_t)ib * NB; ldc = lda; }
   if (first) tile_writeback<T, WB_STORE>(acc, C, ldc, smem);
   else tile_writeback<T, WB_ADD>(acc, C, ldc, smem);
+}
+
+// The same on the split engine (fp32): the operands are the planes of the group's rows of W that the group panel and
+// k_wtri_planes already wrote into the rolling buffer `Pl` (rows 128 (l - g0) .., columns wcol0 + ..; family SC_SW), so the
+// accumulation needs no pass over W of its own.  Macro tile = K^-1 tiles (ibm, jb) and (ibm + 1, jb): both live at block row
+// jb of the lower triangle, side by side.  grid (g1, (g1 + 1) / 2, q); workgroups above the diagonal leave at once.
+template <class S>
+__global__ __launch_bounds__(B3_NT, 2) void k_kacc_bf3(float *A, int64_t lda, int64_t strideA, float *Kd, int64_t strideKd,
+                                                       const unsigned short *__restrict__ Pl, int64_t pl_lat_stride, int64_t wcol0, int g0, int g1,
+                                                       const float *__restrict__ sc, int64_t sc_stride) {
+  __shared__ __align__(16) unsigned char lds[b3_lds_bytes<S>()];
+  const int jb = blockIdx.x, ibm = 2 * (int)blockIdx.y, lat = blockIdx.z;
+  if (ibm > jb) return;
+  const bool first = jb >= g0;
+  const int r0 = first ? jb : g0;
+  const float sW = sc[(int64_t)lat * sc_stride + SC_SW];
+  const unsigned short *Pr = Pl + (int64_t)lat * pl_lat_stride + b3_index<S>((int64_t)(r0 - g0) * NB, 0, wcol0, lda);
+  const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), ib = ibm + half;
+  const bool live = ib <= jb;
+  float *C;
+  int64_t ldc;
+  if (ib == jb) { C = Kd + (int64_t)lat * strideKd + (int64_t)ib * NB * NB; ldc = NB; }
+  else { C = A + (int64_t)lat * strideA + (int64_t)jb * NB * lda + (int64_t)ib * NB; ldc = lda; }
+  float *stg = reinterpret_cast<float *>(lds + half * B3_WB_BYTES);
+  const int tid = (int)threadIdx.x & 255;
+  Acc<float> acc0, acc1;
+  acc0.zero();
+  acc1.zero();
+  f32x4 vc0[B3_WB_NCH];
+  auto pre = [&]() { b3_preload(vc0, C, ldc, tid, live && !first); };
+  b3_mainloop<S, 2, B3_WB_NCH>(acc0, acc1, Pr + (int64_t)ibm * NB * 8, lda, Pr + (int64_t)jb * NB * 8, lda, (g1 - r0) * NB, lds, pre);
+  b3_combine<S>(acc0, acc1, 1.0f / (sW * sW));
+  if (first) b3_writeback<S, WB_STORE, false>(acc0, C, ldc, stg, tid, live);
+  else b3_writeback<S, WB_ADD, false, true>(acc0, C, ldc, stg, tid, live, nullptr, 0, true, 1.0f, vc0);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -937,7 +974,12 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     double fl = 0.0;
     for (int jb = 0; jb < g1; ++jb) fl += (jb + 0.5) * 2.0 * nb * nb * (double)(g1 - (jb >= g0 ? jb : g0)) * nb;   // diagonal tiles: half
     ProfScope ps(PK_KACC, s, q * fl, q * (2.0 * nt - (double)(g1 - g0) * (g0 + g1 + 1) / 2.0) * nb * nb * esz);
-    hipLaunchKernelGGL((k_kacc<T>), dim3(nt, q), dim3(NTHREADS), bulk_lds, s, A, lda, strideA, (const T *)WA, lda, strideA, Kd, strideV, g0, g1);
+    if constexpr (bf3) {
+      hipLaunchKernelGGL((k_kacc_bf3<SS>), dim3(g1, (g1 + 1) / 2, q), dim3(B3_NT), 0, s, (float *)A, lda, strideA, (float *)Kd, strideV,
+                         (const unsigned short *)planes(g0), pl_lat, wcol0, g0, g1, (const float *)scl, sc_lat);
+    } else {
+      hipLaunchKernelGGL((k_kacc<T>), dim3(nt, q), dim3(NTHREADS), bulk_lds, s, A, lda, strideA, (const T *)WA, lda, strideA, Kd, strideV, g0, g1);
+    }
   };
 
   // PLMC_BULK_STREAMS=1: the group panel of the other columns and the head rows ride on the caller's stream, in front of the tail
@@ -948,6 +990,11 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // serialised the chain behind bulk launches: sweep + accumulation took exactly the sum of the two.
   hipEvent_t e_entry = sync_event(0), e_v = sync_event(1), e_gh = sync_event(2), e_p = sync_event(3), e_hd = sync_event(4),
              e_tail = sync_event(5), e_doneC = sync_event(6), e_doneH = sync_event(7), e_prev = sync_event(8);
+  // split engine: the accumulation reads the planes of the group's rows (rolling buffer gi & 1) and is pure filler, so it gets
+  // a (low-priority) stream of its own behind e_p; the panels of group gi + 2, which overwrite that buffer, wait for e_k[gi & 1]
+  hipStream_t K = (serial || !kacc_on || !bf3) ? nullptr : side_stream(2);
+  hipEvent_t e_k[2] = {sync_event(9), sync_event(10)}, e_doneK = sync_event(11);
+  if (!(e_k[0] && e_k[1] && e_doneK)) K = nullptr;
   const bool la = C && H && e_entry && e_v && e_gh && e_p && e_hd && e_tail && e_doneC && e_doneH && e_prev && ng > 2;
   if (!la) {
     // one stream: chain -> transpose -> group panel over every column -> trailing update of every row below
@@ -1013,15 +1060,22 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     vtrans(gi, C);
     (void)hipEventRecord(e_v, C);
     if (gi > 0 || bf3) (void)hipStreamWaitEvent(C, e_hd, 0);                   // head(gi - 1): rows R0 final (split engine: and their raw planes)
+    if (K && gi >= 2) (void)hipStreamWaitEvent(C, e_k[gi & 1], 0);             // kacc(gi - 2) has read the plane buffer this panel writes
     gpanel(g0, G, cm_buf(g1, g2 - g1, 0, 0, 0), Vg, C, 1);                      // head columns R1
     (void)hipEventRecord(e_gh, C);
     if (gi > 0) (void)hipStreamWaitEvent(C, e_tail, 0);                        // tail(gi - 1): rows R1 up to date
     update(g1, g2 - g1, g0, g1 - 1, cm_buf(g1, g2 - g1, 0, 0, 0), C, PK_TRAIL_HEAD, 0, 0, true);   // U1: next triangle
 
     (void)hipStreamWaitEvent(H, e_v, 0);
+    if (K && gi >= 2) (void)hipStreamWaitEvent(H, e_k[gi & 1], 0);
     wtri_planes(gi, H);
     gpanel(g0, G, cm_buf(g2, m - g2, Taug, 0, g0), Vg, H, 0);                   // rest of the panel columns
     (void)hipEventRecord(e_p, H);
+    if (K) {                                                                   // rows R0 of W are final and in planes: filler work
+      (void)hipStreamWaitEvent(K, e_p, 0);
+      kacc(gi, K);
+      (void)hipEventRecord(e_k[gi & 1], K);
+    }
     (void)hipStreamWaitEvent(H, e_gh, 0);
     if (gi > 0) (void)hipStreamWaitEvent(H, e_tail, 0);
     update(g1, g2 - g1, g0, g1 - 1, cm_buf(g2, m - g2, Taug, 0, g1), H, PK_TRAIL_HEAD, 0, 0, false, g2);   // head: rows R1, columns right of R1
@@ -1031,7 +1085,11 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     (void)hipStreamWaitEvent(st, e_gh, 0);
     update(g2, m - g2, g0, g1 - 1, cm_buf(g2, m - g2, Taug, 0, g1), st, PK_TRAIL);         // tail: rows below R1
     (void)hipEventRecord(e_tail, st);
-    kacc(gi, st);            // rows R0 of the inverse factor are final (e_p: panel copy; e_gh is behind vtrans): filler work
+    if (!K) kacc(gi, st);    // rows R0 of the inverse factor are final (e_p: panel copy; e_gh is behind vtrans): filler work
+  }
+  if (K) {
+    (void)hipEventRecord(e_doneK, K);
+    (void)hipStreamWaitEvent(st, e_doneK, 0);
   }
   (void)hipEventRecord(e_doneC, C);
   (void)hipEventRecord(e_doneH, H);

@@ -140,11 +140,15 @@ def factorize(kind, X, ell, oscale, noise, rhs, ws, Xs=None, kacc=False):
 
 
 def sweep_accumulates_kinv():
-    """PLMC_KINV_IN_SWEEP=1: the sweep accumulates Khat^-1 = W^T W group by group (plmc_potrf with_inverse = 2) and the
-    gradient is one HBM-bound pass over it (plmc_grad_tiles).  Default: one fused K^-1 + gradient kernel behind the
-    sweep (plmc_kinv_grad) on the gradient stream.  Measured on MI355X (n = 8192, fp32; ms/step fused vs in-sweep):
-    q = 8 37.4 / 37.4, q = 4 19.6 / 20.3, q = 2 11.2 / 11.7, q = 1 7.6 / 8.3 -- the accumulation does not hide behind the
-    latency-bound end of the sweep, it slows the chain it runs beside, so it stays an option."""
+    """PLMC_KINV_IN_SWEEP=1: the sweep accumulates Khat^-1 = W^T W group by group (plmc_potrf with_inverse = 2; fp32: on the
+    split engine from the planes of the group's rows of W, on a low-priority stream of its own) and the gradient is one
+    HBM-bound pass over it (plmc_grad_tiles).  Default: one fused K^-1 + gradient kernel behind the sweep (plmc_kinv_grad)
+    on the gradient stream.  Measured on MI355X (n = 8192, fp32; ms/step fused vs in-sweep), round 3 / split engine:
+    q = 8 18.7 / 19.4, q = 2 6.26 / 6.24, q = 1 4.77 / 4.78 (round 2 / fp32 MFMA engine: 37.4 / 37.4, 11.2 / 11.7,
+    7.6 / 8.3).  The accumulation does not hide: W is lower triangular, so (g + 1)^2 / 204 of the work belongs to group g --
+    54 % of it only becomes available with the last two of eight groups -- and until then the bulk stream is busy back to
+    back anyway (profiles/r03_sweep_phases_q8_kinv_in_sweep.txt); beside the chain it slows the chain.  It stays an
+    option."""
     return os.environ.get("PLMC_KINV_IN_SWEEP", "0") == "1"
 
 

@@ -87,7 +87,7 @@ def _multi_group_body(eng, n, d, q):
 
 
 @pytest.mark.parametrize("n,d,q", [(1000, 8, 2), (2300, 12, 3), (4200, 5, 2)])
-def test_split_engines_against_fp32_mfma_path(eng, n, d, q):
+def test_split_engines_against_fp32_mfma_path(eng, n, d, q, monkeypatch):
     """Arithmetic of the bulk fp32 products (the depth-1024 trailing updates and group panels of the sweep, from three groups
     of block rows on, and the W^T W products of the gradient kernel; csrc/bf3_engine.hpp):
       default (PLMC_SPLIT=2): two fp16 planes per operand, scaled by bounds from the diagonal and the noise, three plane
@@ -116,7 +116,14 @@ def test_split_engines_against_fp32_mfma_path(eng, n, d, q):
         b3 = run()
     with _hip.knob("PLMC_SPLIT", "0"):
         plain = run()
-    for split in (h2, b3):
+    # K^-1 accumulated group by group inside the sweep (split engine: from the planes of the group's rows of W, on a filler
+    # stream) + the one-pass gradient kernel, instead of the fused K^-1 + gradient kernel behind the sweep
+    monkeypatch.setenv("PLMC_KINV_IN_SWEEP", "1")
+    h2_in_sweep = run()
+    with _hip.knob("PLMC_SPLIT", "3"):
+        b3_in_sweep = run()
+    monkeypatch.delenv("PLMC_KINV_IN_SWEEP")
+    for split in (h2, b3, h2_in_sweep, b3_in_sweep):
         for got, base, want, tol in ((split[0], plain[0], ref[0], 1e-4), (split[1], plain[1], ref[1], 2e-3),
                                      (split[2], plain[2], ref[2], 2e-3), (split[3], plain[3], ref[4], 2e-3)):
             scale = want.abs().max()
