@@ -52,15 +52,19 @@ int64_t     plmc_pad(int64_t n);              /* n rounded up to a multiple of N
 int         plmc_max_dim(void);               /* largest input dimension d accepted by the fused kernels */
 const char *plmc_last_error(void);            /* text of the last error on the calling thread */
 /* NB x NB blocks per latent the `Vd` argument of plmc_potrf_* must hold, for elements of `elem_bytes` (4 or 8) bytes.  The
- * sizes never depend on the dev knobs (version 3: for 4-byte elements they always include the bf16 plane buffers of the
- * bf16 engine, on or off).  plmc_vd_blocks(n_pad, lda) = the 4-byte count (the larger one: safe for both).
- * ABI note: version 1 sized Vd as n_pad / NB blocks -- a caller built against it must re-query. */
+ * sizes depend on (n_pad, lda, elem_bytes) only, never on the dev knobs (version 3: for 4-byte elements they always include
+ * the plane buffers of the split engine, on or off; version 4: and, when lda has room for the inverse factor
+ * (lda >= 2 n_pad), the full-height planes of W that plmc_kinv_grad_vd_* reads, 6 n_pad^2 bytes).
+ * plmc_vd_blocks(n_pad, lda) = the 4-byte count (the larger one: safe for both).
+ * ABI note: versions 1-3 sized Vd smaller -- a caller built against them must re-query (check plmc_version() == 4). */
 int64_t     plmc_vd_blocks_for(int64_t n_pad, int64_t lda, int elem_bytes);
 int64_t     plmc_vd_blocks(int64_t n_pad, int64_t lda);
 /* Bytes of the `partials` scratch plmc_kinv_grad_* needs for (n_pad, q): per-tile partial sums, and for 4-byte elements the
  * bf16 planes of W (6 q n_pad^2 bytes).  plmc_grad_scratch_bytes = the 4-byte size. */
 int64_t     plmc_grad_scratch_bytes_for(int64_t n_pad, int q, int elem_bytes);
 int64_t     plmc_grad_scratch_bytes(int64_t n_pad, int q);
+/* ... and what plmc_kinv_grad_vd_* needs (the partial sums only: the planes of W come from the sweep's Vd). */
+int64_t     plmc_grad_partials_bytes(int64_t n_pad, int q);
 
 /*
  * Covariance assembly.  Replaces `self.covar_module(x)` (:316, :1090; kernels built by
@@ -241,6 +245,22 @@ int plmc_kinv_grad_ex_f64(int kind, const double *W, int64_t n_pad, int64_t ldw,
                           const double *alpha, const double *X, int n, int d, const double *ell,
                           const double *oscale, double *grad, double *Kinv, int64_t ldk, int64_t strideK,
                           double *kinv_diag, void *partials, int q, const double *eig_lo, void *stream);
+/* The same for a W that is still where its sweep left it: W = the inverse-factor columns of the factor buffer (ldw = that
+ * buffer's lda), Vd = the scratch of that plmc_potrf_ex_* call (with_inverse != 0), untouched since.  The sweep's
+ * epilogues have already written the 16-bit planes of W into Vd (the rows of a group the moment they are final), so the
+ * split pass over W of the entry points above is skipped (0.6 ms of the 19 ms step at the metric shape) and `partials`
+ * only needs plmc_grad_partials_bytes(n_pad, q).  Both calls must see the same PLMC_SPLIT and both or neither an eig_lo:
+ * the scratch records which scheme wrote it and a mismatch yields NaN gradients, not silently wrong ones.  Vd = NULL, fp64,
+ * PLMC_SPLIT=0 or a layout without inverse-factor columns: exactly plmc_kinv_grad_ex_* (then `partials` must have the
+ * full plmc_grad_scratch_bytes_for size). */
+int plmc_kinv_grad_vd_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW,
+                          const float *alpha, const float *X, int n, int d, const float *ell,
+                          const float *oscale, double *grad, float *Kinv, int64_t ldk, int64_t strideK,
+                          float *kinv_diag, void *partials, int q, const float *eig_lo, const float *Vd, void *stream);
+int plmc_kinv_grad_vd_f64(int kind, const double *W, int64_t n_pad, int64_t ldw, int64_t strideW,
+                          const double *alpha, const double *X, int n, int d, const double *ell,
+                          const double *oscale, double *grad, double *Kinv, int64_t ldk, int64_t strideK,
+                          double *kinv_diag, void *partials, int q, const double *eig_lo, const double *Vd, void *stream);
 
 /*
  * Exact (dense) LMC / ICM: Kronecker-structured coregionalisation.

@@ -49,28 +49,69 @@ const Knobs &knobs() {
   return g_knobs;
 }
 
-// ---- helper stream + ordering events for the look-ahead of the blocked sweep (one per device,
-// created on first use; together with the profiler record this is all the process-global state).
-static hipStream_t g_side[64][3] = {{nullptr}};
-static hipEvent_t g_sync[64][16] = {{nullptr}};
-// which: 0 = the chain (highest priority: its small launches must get CU slots ahead of queued bulk tiles), 1 = the group
-// panel + head rows (high), 2 = the K^-1 accumulation (default priority: filler work)
-hipStream_t side_stream(int which) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || which < 0 || which > 2) return nullptr;
-  if (!g_side[dev][which]) {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (hipStreamCreateWithPriority(&g_side[dev][which], hipStreamNonBlocking, which == 2 ? lo : hi) != hipSuccess) g_side[dev][which] = nullptr;
-  }
-  return g_side[dev][which];
-}
-hipEvent_t sync_event(int idx) {
+// ---- helper streams + ordering events for the look-ahead of the blocked sweep: SWEEP_CTX sets per device, created on
+// first use (together with the profiler record this is all the process-global state).  A sweep uses the set bound to its
+// CALLER stream (bind_sweep_ctx): sweeps queued on one stream are ordered by the stream and share a set; sweeps from two
+// different streams get a set each and may overlap on the device (what _engine.py does with the two halves of the latents);
+// a third stream takes over the least recently used set and first waits for that set's last sweep (its e_prev event).
+constexpr int SWEEP_CTX = 2;
+struct SweepCtx {
+  hipStream_t caller = nullptr;
+  bool used = false;
+  unsigned long long stamp = 0;
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[16] = {nullptr};
+};
+static SweepCtx g_ctx[64][SWEEP_CTX];
+static unsigned long long g_stamp = 0;
+static thread_local int t_ctx = 0;
+static SweepCtx *cur_ctx() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  hipEvent_t &e = g_sync[dev][idx & 15];
+  return &g_ctx[dev][t_ctx];
+}
+// which: 0 = the chain (highest priority: its small launches must get CU slots ahead of queued bulk tiles), 1 = the group
+// panel + head rows (high), 2 = the K^-1 accumulation (lowest priority: filler work)
+hipStream_t side_stream(int which) {
+  SweepCtx *c = cur_ctx();
+  if (!c || which < 0 || which > 2) return nullptr;
+  if (!c->side[which]) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&c->side[which], hipStreamNonBlocking, which == 2 ? lo : hi) != hipSuccess) c->side[which] = nullptr;
+  }
+  return c->side[which];
+}
+hipEvent_t sync_event(int idx) {
+  SweepCtx *c = cur_ctx();
+  if (!c) return nullptr;
+  hipEvent_t &e = c->ev[idx & 15];
   if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
   return e;
+}
+// Select the set of `caller` for the following side_stream / sync_event calls of this thread.  `e_prev_idx`: index of the
+// event a sweep records on its caller stream when everything it queued is behind that point.
+void bind_sweep_ctx(hipStream_t caller, int e_prev_idx) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { t_ctx = 0; return; }
+  SweepCtx *set = g_ctx[dev];
+  int pick = -1;
+  for (int i = 0; i < SWEEP_CTX; ++i)
+    if (set[i].used && set[i].caller == caller) pick = i;
+  if (pick < 0) {
+    for (int i = 0; i < SWEEP_CTX && pick < 0; ++i)
+      if (!set[i].used) pick = i;
+    if (pick < 0) {
+      pick = 0;
+      for (int i = 1; i < SWEEP_CTX; ++i)
+        if (set[i].stamp < set[pick].stamp) pick = i;
+      if (set[pick].ev[e_prev_idx & 15]) (void)hipStreamWaitEvent(caller, set[pick].ev[e_prev_idx & 15], 0);   // that set's last sweep
+    }
+    set[pick].caller = caller;
+    set[pick].used = true;
+  }
+  set[pick].stamp = ++g_stamp;
+  t_ctx = pick;
 }
 
 // Bare MFMA stream (no memory traffic): 16 independent accumulators per wave, 4 waves per SIMD -- the rate the matrix
@@ -160,7 +201,7 @@ ProfScope::~ProfScope() {
 }  // namespace plmc
 
 extern "C" {
-int plmc_version(void) { return 3; }   // 3: Vd / gradient scratch sizes independent of the knobs (+ plmc_*_for), k8-ordered bf16 planes
+int plmc_version(void) { return 4; }   // 4: Vd carries the full-height planes of W (plmc_kinv_grad_vd_*, plmc_grad_partials_bytes); 3: Vd / gradient scratch sizes independent of the knobs (+ plmc_*_for), k8-ordered bf16 planes
 int plmc_block(void) { return plmc::NB; }
 int64_t plmc_pad(int64_t n) { return (n + plmc::NB - 1) / plmc::NB * plmc::NB; }
 int plmc_max_dim(void) { return plmc::MAX_DIM; }

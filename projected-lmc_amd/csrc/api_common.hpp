@@ -61,6 +61,17 @@ const Knobs &knobs();
 
 hipStream_t side_stream(int which = 0);   // per-device helper streams (api.hip), which in {0, 1, 2}; nullptr on failure
 hipEvent_t sync_event(int idx);     // per-device ordering events, idx in [0,16)
+void bind_sweep_ctx(hipStream_t caller, int e_prev_idx);   // select the stream / event set of this caller stream (api.hip)
+
+// NB x NB blocks (4-byte elements) of the full-height W planes inside Vd: 3 planes x 2 bytes x n_pad^2 (the three-plane
+// scheme's size, whatever the scheme), only for 4-byte elements and a layout with inverse-factor columns (lda >= 2 n_pad)
+inline int64_t vd_wk_blocks(int64_t n_pad, int64_t lda, int elem_bytes) {
+  const int64_t m = n_pad / 128;
+  return (elem_bytes == 4 && lda >= 2 * n_pad) ? (3 * m * m + 1) / 2 : 0;
+}
+constexpr int VD_W_TAG = 8 + 3 * 32 - 1;   // floats from the W-family scale (vd_w_planes: *w_scale) to the scheme tag (planes per element) of that scratch
+bool vd_w_planes(const float *Vd, int64_t n_pad, int64_t lda, const unsigned short **wk, int64_t *wk_lat_stride, const float **w_scale,
+                 int64_t *w_scale_lat_stride);                              // potrf.hip
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
 }
 
 // ---- scales of the split engine's operand families (bf3_engine.hpp).  Per latent eight floats in the Vd scratch:
-enum { SC_SU = 0, SC_SW = 1, SC_RU = 2, SC_RW = 3, SC_SA = 4, SC_RA = 5, SC_N = 8 };
+enum { SC_SU = 0, SC_SW = 1, SC_RU = 2, SC_RW = 3, SC_SA = 4, SC_RA = 5, SC_N = 8, SC_TAG = 8 + 3 * 32 };   // SC_TAG: behind the scan partials (3 SCAN_PARTS)
 //   SU solved rows, U columns:      |U_kj| <= sqrt(A_jj) <= sqrt(D),  D = largest diagonal entry of the input
 //   SW solved rows, W columns, and the inverse triangle Vgg:   |W_ij| <= ||U^-1||_2 = 1 / sqrt(lambda_min)
 //   RU raw rows (before their panel solve), U columns: entries of Schur complements, <= D
@@ -197,6 +197,7 @@ template <class S>
 __global__ __launch_bounds__(64) void k_split_scales(int64_t n_pad, const float *__restrict__ eig_lo, float *__restrict__ sc, int64_t sc_stride) {
   const int lat = blockIdx.x;
   float *o = sc + (int64_t)lat * sc_stride;
+  if (threadIdx.x == 0) o[SC_TAG] = (float)S::NPL;               // which scheme wrote the planes of this scratch (checked by the K^-1 kernel)
   if constexpr (S::NPL == 3) {
     if (threadIdx.x < SC_N) o[threadIdx.x] = 1.0f;
   } else {
@@ -234,7 +235,8 @@ template <class S, int ROLE>
 __global__ __launch_bounds__(B3_NT, 2) void k_update_bf3(float *A, int64_t lda, int64_t strideA, int ib0, int nrows, int r_lo, int r_hi,
                                                          ColMap<float> cm, int skip_ib, int skip_jb, const unsigned short *__restrict__ Pl,
                                                          int64_t pl_lat_stride, int64_t wcol0, unsigned short *__restrict__ Praw,
-                                                         int64_t praw_lat_stride, int raw_end, const float *__restrict__ sc, int64_t sc_stride) {
+                                                         int64_t praw_lat_stride, int raw_end, const float *__restrict__ sc, int64_t sc_stride,
+                                                         const unsigned short *__restrict__ Wk, int64_t wk_lat_stride) {
   if (ROLE == 2 || ROLE == 3) __builtin_amdgcn_s_setprio(2);
   __shared__ __align__(16) unsigned char lds[b3_lds_bytes<S>()];
   const int bx = blockIdx.x, ibm = ib0 + 2 * (int)blockIdx.y, lat = blockIdx.z;
@@ -278,7 +280,12 @@ __global__ __launch_bounds__(B3_NT, 2) void k_update_bf3(float *A, int64_t lda, 
   // the C rows of the first write-back pass are requested two stages before the main loop ends (nothing for a first touch)
   f32x4 vc0[B3_WB_NCH];
   auto pre = [&]() { b3_preload(vc0, C, ldc, tid, live && !first); };
-  b3_mainloop<S, 2, B3_WB_NCH>(acc0, acc1, Pr + (int64_t)ibm * NB * 8, lda, Pr + colp * 8, lda, depth, lds, pre);
+  // B operand: the column's planes of the group's rows -- U / augmented columns in the rolling buffer, inverse-factor columns in
+  // the full-height planes of W (global row index, n_pad columns per plane row)
+  const unsigned short *Bp = Pr + colp * 8;
+  int64_t ldb = lda;
+  if (bx >= cm.nU + cm.Taug) { Bp = Wk + (int64_t)lat * wk_lat_stride + b3_index<S>(kr0, 0, col0, cm.n_pad); ldb = cm.n_pad; }
+  b3_mainloop<S, 2, B3_WB_NCH>(acc0, acc1, Pr + (int64_t)ibm * NB * 8, lda, Bp, ldb, depth, lds, pre);
   b3_combine<S>(acc0, acc1, 1.0f / (scl[SC_SU] * sB));
   if (Praw && ibm < raw_end) {              // uniform per workgroup; a half at or beyond raw_end writes no planes
     unsigned short *Pp = Praw + (int64_t)lat * praw_lat_stride + b3_index<S>((int64_t)(ibm + half - ib0) * NB, 0, colp, lda);
@@ -440,18 +447,19 @@ __global__ __launch_bounds__(NTHREADS) void k_vtrans(const T *__restrict__ Wg, i
   }
 }
 
-// PLMC_BF16X3 (fp32): the group's inverse triangle W[g0 + i][g0 + k] (k <= i < G, already in the factor buffer's W columns:
-// k_vtrans) as k8-ordered bf16 planes of the rolling buffer (rows 128 i .., column wcol0 + 128 (g0 + k)): the operands of the
-// first-touch W tiles of the tail / head updates.  Off the chain's stream.  grid (G (G + 1) / 2, q).
+// Split engine (fp32): the group's inverse triangle W[g0 + i][g0 + k] (k <= i < G, already in the factor buffer's W columns:
+// k_vtrans) as k8-ordered planes of the full-height plane buffer of W (row 128 (g0 + i) .., column 128 (g0 + k)): the operands
+// of the first-touch W tiles of the tail / head updates and, later, of the K^-1 kernel.  Off the chain's stream.
+// grid (G (G + 1) / 2, q).
 template <class S>
 __global__ __launch_bounds__(NTHREADS) void k_wtri_planes(const float *__restrict__ WA, int64_t lda, int64_t strideA, int g0,
-                                                          unsigned short *__restrict__ Pl, int64_t pl_lat_stride, int64_t wcol0,
-                                                          const float *__restrict__ sc, int64_t sc_stride) {
+                                                          const float *__restrict__ sc, int64_t sc_stride, unsigned short *__restrict__ Wk,
+                                                          int64_t wk_lat_stride, int64_t n_pad) {
   const int lat = blockIdx.y;
   int i = 0, k = (int)blockIdx.x;
   while (k > i) { k -= i + 1; ++i; }
   b3_split_block<S, false>(WA + (int64_t)lat * strideA + (int64_t)(g0 + i) * NB * lda + (int64_t)(g0 + k) * NB, lda,
-                           Pl + (int64_t)lat * pl_lat_stride + b3_index<S>((int64_t)i * NB, 0, wcol0 + (int64_t)(g0 + k) * NB, lda), lda,
+                           Wk + (int64_t)lat * wk_lat_stride + b3_index<S>((int64_t)(g0 + i) * NB, 0, (int64_t)(g0 + k) * NB, n_pad), n_pad,
                            sc[(int64_t)lat * sc_stride + SC_SW], nullptr, 0, threadIdx.x);
 }
 
@@ -490,7 +498,8 @@ __global__ __launch_bounds__(B3_NT, 2) void k_gpanel_bf3(float *A, int64_t lda, 
                                                          const unsigned short *__restrict__ VgP, int64_t vgp_lat_stride,
                                                          const unsigned short *__restrict__ Praw, int64_t praw_lat_stride,
                                                          unsigned short *__restrict__ Pl, int64_t pl_lat_stride, int64_t wcol0,
-                                                         const float *__restrict__ sc, int64_t sc_stride, int paired) {
+                                                         const float *__restrict__ sc, int64_t sc_stride, int paired,
+                                                         unsigned short *__restrict__ Wk, int64_t wk_lat_stride) {
   if (!paired) __builtin_amdgcn_s_setprio(2);                         // the head columns: the next chain waits for them
   __shared__ __align__(16) unsigned char lds[b3_lds_bytes<S>()];
   const int lat = blockIdx.z, t = blockIdx.x, y = blockIdx.y;
@@ -509,7 +518,12 @@ __global__ __launch_bounds__(B3_NT, 2) void k_gpanel_bf3(float *A, int64_t lda, 
   }
   const int nm = (G + 1) / 2;
   const unsigned short *Vp = VgP + (int64_t)lat * vgp_lat_stride, *Rp = Praw + (int64_t)lat * praw_lat_stride + colp * 8;
+  // planes of the result: U and augmented columns into the rolling buffer of this group's rows (lda columns per plane row); the
+  // inverse-factor columns -- final here -- into the FULL-HEIGHT planes of W (n_pad columns per plane row), which the trailing
+  // updates and, after the sweep, the K^-1 kernel read
   unsigned short *Pp = Pl + (int64_t)lat * pl_lat_stride + colp * 8;
+  int64_t pld = lda;
+  if (fam == 1) { Pp = Wk + (int64_t)lat * wk_lat_stride + b3_index<S>((int64_t)g0 * NB, 0, colp - wcol0, cm.n_pad); pld = cm.n_pad; }
   const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), tid = (int)threadIdx.x & 255;
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
@@ -523,7 +537,7 @@ __global__ __launch_bounds__(B3_NT, 2) void k_gpanel_bf3(float *A, int64_t lda, 
     b3_combine<S>(acc0, acc1, unscale);
     const int i = i0 + half;
     b3_writeback<S, WB_STORE, true>(acc0, D + (int64_t)i * NB * ldd, ldd, reinterpret_cast<float *>(lds + half * B3_WB_BYTES), tid, half < rows,
-                                    Pp + (int64_t)i * 16 * S::NPL * lda * 8, lda, true, pscale);
+                                    Pp + (int64_t)i * 16 * S::NPL * pld * 8, pld, true, pscale);
     __syncthreads();                     // staging areas free before the next product's DMA lands
   }
 }
@@ -560,12 +574,12 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_kacc(T *A, int6
 }
 
 // The same on the split engine (fp32): the operands are the planes of the group's rows of W that the group panel and
-// k_wtri_planes already wrote into the rolling buffer `Pl` (rows 128 (l - g0) .., columns wcol0 + ..; family SC_SW), so the
-// accumulation needs no pass over W of its own.  Macro tile = K^-1 tiles (ibm, jb) and (ibm + 1, jb): both live at block row
+// k_wtri_planes already wrote into the full-height plane buffer `Wk` (family SC_SW), so the accumulation needs no pass over W
+// of its own.  Macro tile = K^-1 tiles (ibm, jb) and (ibm + 1, jb): both live at block row
 // jb of the lower triangle, side by side.  grid (g1, (g1 + 1) / 2, q); workgroups above the diagonal leave at once.
 template <class S>
 __global__ __launch_bounds__(B3_NT, 2) void k_kacc_bf3(float *A, int64_t lda, int64_t strideA, float *Kd, int64_t strideKd,
-                                                       const unsigned short *__restrict__ Pl, int64_t pl_lat_stride, int64_t wcol0, int g0, int g1,
+                                                       const unsigned short *__restrict__ Wk, int64_t wk_lat_stride, int64_t n_pad, int g0, int g1,
                                                        const float *__restrict__ sc, int64_t sc_stride) {
   __shared__ __align__(16) unsigned char lds[b3_lds_bytes<S>()];
   const int jb = blockIdx.x, ibm = 2 * (int)blockIdx.y, lat = blockIdx.z;
@@ -573,7 +587,7 @@ __global__ __launch_bounds__(B3_NT, 2) void k_kacc_bf3(float *A, int64_t lda, in
   const bool first = jb >= g0;
   const int r0 = first ? jb : g0;
   const float sW = sc[(int64_t)lat * sc_stride + SC_SW];
-  const unsigned short *Pr = Pl + (int64_t)lat * pl_lat_stride + b3_index<S>((int64_t)(r0 - g0) * NB, 0, wcol0, lda);
+  const unsigned short *Pr = Wk + (int64_t)lat * wk_lat_stride + b3_index<S>((int64_t)r0 * NB, 0, 0, n_pad);
   const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), ib = ibm + half;
   const bool live = ib <= jb;
   float *C;
@@ -587,7 +601,7 @@ __global__ __launch_bounds__(B3_NT, 2) void k_kacc_bf3(float *A, int64_t lda, in
   acc1.zero();
   f32x4 vc0[B3_WB_NCH];
   auto pre = [&]() { b3_preload(vc0, C, ldc, tid, live && !first); };
-  b3_mainloop<S, 2, B3_WB_NCH>(acc0, acc1, Pr + (int64_t)ibm * NB * 8, lda, Pr + (int64_t)jb * NB * 8, lda, (g1 - r0) * NB, lds, pre);
+  b3_mainloop<S, 2, B3_WB_NCH>(acc0, acc1, Pr + (int64_t)ibm * NB * 8, n_pad, Pr + (int64_t)jb * NB * 8, n_pad, (g1 - r0) * NB, lds, pre);
   b3_combine<S>(acc0, acc1, 1.0f / (sW * sW));
   if (first) b3_writeback<S, WB_STORE, false>(acc0, C, ldc, stg, tid, live);
   else b3_writeback<S, WB_ADD, false, true>(acc0, C, ldc, stg, tid, live, nullptr, 0, true, 1.0f, vc0);
@@ -735,6 +749,10 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   unsigned short *const Praw = bf3 ? Pl0 + 2 * pl_buf : nullptr;         // raw rows of the group whose panel comes next (one group)
   unsigned short *const VgP = bf3 ? Praw + pl_buf : nullptr;             // planes of Vgg: 128 GMAX x 128 GMAX
   float *const scl = bf3 ? reinterpret_cast<float *>(VgP + b3_elems<SplitB3>((int64_t)GMAX * NB, (int64_t)GMAX * NB)) : nullptr;   // SC_N floats
+  // ... and, with the inverse factor, the full-height planes of W (n_pad columns per plane row) that plmc_kinv_grad_vd_* reads:
+  // written by the same epilogues that write the rolling buffer, so the K^-1 kernel needs no split pass over W
+  unsigned short *const Wk = (bf3 && with_inverse && vd_wk_blocks(n_pad, lda, (int)sizeof(T)) > 0)
+                                 ? reinterpret_cast<unsigned short *>(reinterpret_cast<float *>(scl) + (int64_t)NB * NB) : nullptr;
   const int64_t pl_lat = strideV * (int64_t)(sizeof(T) / 2);            // latent stride in 16-bit elements
   const int64_t sc_lat = strideV * (int64_t)sizeof(T) / 4;              // ... in floats
   const int grp_rows = (knobs().grp > 0 && knobs().grp < GMAX) ? knobs().grp : GMAX;   // block rows per group (as below)
@@ -837,13 +855,13 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
         if (cnb > 0) {
           if (cls == PK_TRAIL)
             hipLaunchKernelGGL((k_update_bf3<SS, 0>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cb, skip_ib, skip_jb, pl, pl_lat,
-                               wcol0, Praw, pl_lat, raw_end, (const float *)scl, sc_lat);
+                               wcol0, Praw, pl_lat, raw_end, (const float *)scl, sc_lat, Wk, pl_lat);
           else if (crit)
             hipLaunchKernelGGL((k_update_bf3<SS, 2>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cb, skip_ib, skip_jb, pl, pl_lat,
-                               wcol0, Praw, pl_lat, raw_end, (const float *)scl, sc_lat);
+                               wcol0, Praw, pl_lat, raw_end, (const float *)scl, sc_lat, Wk, pl_lat);
           else
             hipLaunchKernelGGL((k_update_bf3<SS, 3>), gridb, dim3(B3_NT), 0, s, A, lda, strideA, ib0, nrows, r_lo, r_hi, cb, skip_ib, skip_jb, pl, pl_lat,
-                               wcol0, Praw, pl_lat, raw_end, (const float *)scl, sc_lat);
+                               wcol0, Praw, pl_lat, raw_end, (const float *)scl, sc_lat, Wk, pl_lat);
         }
         if (aug_fp32) fp32_launch(ca);
         return;
@@ -878,7 +896,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       if (nb_ > 0)
         hipLaunchKernelGGL((k_gpanel_bf3<SS>), dim3(nb_, head ? nm : (nm + 1) / 2, q), dim3(B3_NT), 0, s, A, lda, strideA, g0, G, cb,
                            (const unsigned short *)VgP, pl_lat, (const unsigned short *)Praw, pl_lat, planes(g0), pl_lat, wcol0, (const float *)scl, sc_lat,
-                           head ? 0 : 1);
+                           head ? 0 : 1, Wk, pl_lat);
       if (aug_fp32) fp32_panel(ca);
       return;
     }
@@ -951,8 +969,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     if constexpr (bf3) {
       if (!WA) return;
       const int g0 = G0(gi), G = G0(gi + 1) - g0;
-      hipLaunchKernelGGL((k_wtri_planes<SS>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const float *)WA, lda, strideA, g0, planes(g0), pl_lat,
-                         wcol0, (const float *)scl, sc_lat);
+      hipLaunchKernelGGL((k_wtri_planes<SS>), dim3(G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const float *)WA, lda, strideA, g0, (const float *)scl, sc_lat, Wk, pl_lat,
+                         n_pad);
     }
   };
   // PLMC_BF16X3: planes of the first group's raw rows (columns of the bulk panel: everything right of the second group + aug)
@@ -976,12 +994,14 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     ProfScope ps(PK_KACC, s, q * fl, q * (2.0 * nt - (double)(g1 - g0) * (g0 + g1 + 1) / 2.0) * nb * nb * esz);
     if constexpr (bf3) {
       hipLaunchKernelGGL((k_kacc_bf3<SS>), dim3(g1, (g1 + 1) / 2, q), dim3(B3_NT), 0, s, (float *)A, lda, strideA, (float *)Kd, strideV,
-                         (const unsigned short *)planes(g0), pl_lat, wcol0, g0, g1, (const float *)scl, sc_lat);
+                         (const unsigned short *)Wk, pl_lat, n_pad, g0, g1, (const float *)scl, sc_lat);
     } else {
       hipLaunchKernelGGL((k_kacc<T>), dim3(nt, q), dim3(NTHREADS), bulk_lds, s, A, lda, strideA, (const T *)WA, lda, strideA, Kd, strideV, g0, g1);
     }
   };
 
+  // the helper streams and ordering events of THIS caller stream (api.hip: sweeps from different streams may overlap)
+  if (!serial) bind_sweep_ctx(st, 8);
   // PLMC_BULK_STREAMS=1: the group panel of the other columns and the head rows ride on the caller's stream, in front of the tail
   hipStream_t C = serial ? nullptr : side_stream(), H = serial ? nullptr : (kn.bulk_streams == 1 ? st : side_stream(1));
   // the K^-1 accumulation rides on the caller's stream behind the tail (e_tail is recorded before it, so nothing on the
@@ -990,11 +1010,11 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // serialised the chain behind bulk launches: sweep + accumulation took exactly the sum of the two.
   hipEvent_t e_entry = sync_event(0), e_v = sync_event(1), e_gh = sync_event(2), e_p = sync_event(3), e_hd = sync_event(4),
              e_tail = sync_event(5), e_doneC = sync_event(6), e_doneH = sync_event(7), e_prev = sync_event(8);
-  // split engine: the accumulation reads the planes of the group's rows (rolling buffer gi & 1) and is pure filler, so it gets
-  // a (low-priority) stream of its own behind e_p; the panels of group gi + 2, which overwrite that buffer, wait for e_k[gi & 1]
+  // split engine: the accumulation reads the full-height planes of W (rows of group gi: final behind e_p, never rewritten) and
+  // is pure filler, so it gets a (low-priority) stream of its own
   hipStream_t K = (serial || !kacc_on || !bf3) ? nullptr : side_stream(2);
-  hipEvent_t e_k[2] = {sync_event(9), sync_event(10)}, e_doneK = sync_event(11);
-  if (!(e_k[0] && e_k[1] && e_doneK)) K = nullptr;
+  hipEvent_t e_doneK = sync_event(11);
+  if (!e_doneK) K = nullptr;
   const bool la = C && H && e_entry && e_v && e_gh && e_p && e_hd && e_tail && e_doneC && e_doneH && e_prev && ng > 2;
   if (!la) {
     // one stream: chain -> transpose -> group panel over every column -> trailing update of every row below
@@ -1036,18 +1056,6 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // gpanel_rest(gi) read: by then C has waited for e_hd(gi), recorded behind it.  U1 / head / tail touch disjoint
   // tiles; every tile receives its updates in the same order as on one stream, so the result is bit-identical to the
   // serial schedule (tests/test_gpu_edges.py).
-  // The helper streams, the ordering events and the group scratch are per DEVICE: a second sweep on this device from ANOTHER
-  // caller stream must not start while the previous one is in flight (same caller stream: stream order does it).
-  {
-    int dev = 0;
-    static hipStream_t last_caller[64] = {nullptr};
-    static bool have_prev[64] = {false};
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-      if (have_prev[dev] && last_caller[dev] != st) (void)hipStreamWaitEvent(st, e_prev, 0);
-      last_caller[dev] = st;
-      have_prev[dev] = true;
-    }
-  }
   (void)hipEventRecord(e_entry, st);
   (void)hipStreamWaitEvent(C, e_entry, 0);
   (void)hipStreamWaitEvent(H, e_entry, 0);
@@ -1060,21 +1068,18 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     vtrans(gi, C);
     (void)hipEventRecord(e_v, C);
     if (gi > 0 || bf3) (void)hipStreamWaitEvent(C, e_hd, 0);                   // head(gi - 1): rows R0 final (split engine: and their raw planes)
-    if (K && gi >= 2) (void)hipStreamWaitEvent(C, e_k[gi & 1], 0);             // kacc(gi - 2) has read the plane buffer this panel writes
     gpanel(g0, G, cm_buf(g1, g2 - g1, 0, 0, 0), Vg, C, 1);                      // head columns R1
     (void)hipEventRecord(e_gh, C);
     if (gi > 0) (void)hipStreamWaitEvent(C, e_tail, 0);                        // tail(gi - 1): rows R1 up to date
     update(g1, g2 - g1, g0, g1 - 1, cm_buf(g1, g2 - g1, 0, 0, 0), C, PK_TRAIL_HEAD, 0, 0, true);   // U1: next triangle
 
     (void)hipStreamWaitEvent(H, e_v, 0);
-    if (K && gi >= 2) (void)hipStreamWaitEvent(H, e_k[gi & 1], 0);
     wtri_planes(gi, H);
     gpanel(g0, G, cm_buf(g2, m - g2, Taug, 0, g0), Vg, H, 0);                   // rest of the panel columns
     (void)hipEventRecord(e_p, H);
     if (K) {                                                                   // rows R0 of W are final and in planes: filler work
       (void)hipStreamWaitEvent(K, e_p, 0);
       kacc(gi, K);
-      (void)hipEventRecord(e_k[gi & 1], K);
     }
     (void)hipStreamWaitEvent(H, e_gh, 0);
     if (gi > 0) (void)hipStreamWaitEvent(H, e_tail, 0);
@@ -1098,6 +1103,26 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   (void)hipEventRecord(e_prev, st);                      // everything of this sweep is behind this point of the caller's stream
 
   return finish();
+}
+
+// Where a sweep of the split engine left the full-height planes of W and the scale of that operand family inside its `Vd`
+// scratch (fp32, layout with inverse-factor columns): for kinv_grad_impl (potri_grad.hip).  Strides per latent: 16-bit
+// elements / floats.  Returns false when the layout has no such planes.
+bool vd_w_planes(const float *Vd, int64_t n_pad, int64_t lda, const unsigned short **wk, int64_t *wk_lat_stride, const float **w_scale,
+                 int64_t *w_scale_lat_stride) {
+  if (vd_wk_blocks(n_pad, lda, 4) <= 0) return false;
+  const int64_t m = n_pad / NB, strideV = plmc_vd_blocks_for(n_pad, lda, 4) * (int64_t)NB * NB;
+  const float *Wg = Vd + m * NB * NB;
+  const float *Pbulk = Wg + 4 * (int64_t)GMAX * NB * LDG;
+  const int64_t pl_buf = b3_elems<SplitB3>((int64_t)GMAX * NB, lda);
+  const unsigned short *Pl0 = reinterpret_cast<const unsigned short *>(Pbulk + (int64_t)GMAX * NB * lda);
+  const unsigned short *VgP = Pl0 + 3 * pl_buf;
+  const float *scl = reinterpret_cast<const float *>(VgP + b3_elems<SplitB3>((int64_t)GMAX * NB, (int64_t)GMAX * NB));
+  *wk = reinterpret_cast<const unsigned short *>(scl + (int64_t)NB * NB);
+  *wk_lat_stride = strideV * 2;
+  *w_scale = scl + SC_SW;                                        // (the scheme tag sits SC_TAG - SC_SW floats behind it)
+  *w_scale_lat_stride = strideV;
+  return true;
 }
 
 // Forward substitution of NEW augmented columns against a factor buffer that plmc_potrf_* already factorised WITH the inverse
@@ -1182,11 +1207,12 @@ extern "C" {
 // on, so that a workspace never depends on a knob.
 int64_t plmc_vd_blocks_for(int64_t n_pad, int64_t lda, int elem_bytes) {
   const int64_t ldb = (lda + plmc::NB - 1) / plmc::NB;
+  // (version 4) + the full-height planes of W for plmc_kinv_grad_vd_*, when the layout has inverse-factor columns
   // planes (4-byte elements): rolling buffer of the solved panel rows (2 groups) + raw rows of the next group (1 group), each
   // 128 GMAX rows x 3 planes x lda x 2 bytes = 12 ldb blocks at GMAX = 8, + Vgg (3 x (128 GMAX)^2 x 2 bytes = 96 blocks)
   // + 1 block holding the scales of the operand families
   const int64_t planes = elem_bytes == 4 ? 3 * (3 * plmc::GMAX * ldb / 2) + 6 * plmc::GMAX * plmc::GMAX / 4 + 1 : 0;
-  return 2 * (n_pad / plmc::NB) + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ldb + planes;
+  return 2 * (n_pad / plmc::NB) + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ldb + planes + plmc::vd_wk_blocks(n_pad, lda, elem_bytes);
 }
 int64_t plmc_vd_blocks(int64_t n_pad, int64_t lda) { return plmc_vd_blocks_for(n_pad, lda, 4); }
 // PLMC_SPLIT picks the arithmetic of the bulk fp32 products: 0 = fp32 MFMA everywhere, 3 = SplitB3, 2 (default) = SplitH2

@@ -187,7 +187,8 @@ template <class S, int DCAP, bool SPLINE = false>
 __global__ __launch_bounds__(B3_NT, 2) void k_kinv_grad_bf3(int kind, int64_t n_pad, const float *__restrict__ alpha, const float *__restrict__ X, int n,
                                                             int d, const float *__restrict__ ell, const float *__restrict__ oscale, float *Kinv,
                                                             int64_t ldk, int64_t strideK, float *kinv_diag, double *__restrict__ partials, int nlat,
-                                                            int plain, const unsigned short *__restrict__ Wp, const float *__restrict__ wscale) {
+                                                            int plain, const unsigned short *__restrict__ Wp, const float *__restrict__ wscale,
+                                                            int64_t wp_lat_stride, int64_t ws_stride) {
   constexpr int LDS_BYTES = b3_lds_bytes<S>() > 2 * tile_smem_elems<float>() * (int)sizeof(float) ? b3_lds_bytes<S>() : 2 * tile_smem_elems<float>() * (int)sizeof(float);
   __shared__ __align__(16) unsigned char lds[LDS_BYTES];
   const int m = (int)(n_pad / NB);
@@ -200,9 +201,12 @@ __global__ __launch_bounds__(B3_NT, 2) void k_kinv_grad_bf3(int kind, int64_t n_
   Acc<float> acc0, acc1;
   acc0.zero();
   acc1.zero();
-  const unsigned short *Pl = Wp + (int64_t)lat * b3_elems<S>(n_pad, n_pad) + b3_index<S>((int64_t)jb * NB, 0, 0, n_pad);
+  const unsigned short *Pl = Wp + (int64_t)lat * wp_lat_stride + b3_index<S>((int64_t)jb * NB, 0, 0, n_pad);
   b3_mainloop<S>(acc0, acc1, Pl + (int64_t)ibm * NB * 8, n_pad, Pl + (int64_t)jb * NB * 8, n_pad, (int)(n_pad - (int64_t)jb * NB), lds);
-  const float ws = wscale[lat];
+  float ws = wscale[(int64_t)lat * ws_stride];
+  // planes taken over from a sweep (ws_stride > 1): they must be of THIS scheme -- a sweep without eig_lo followed by a K^-1 call
+  // with it (or a changed PLMC_SPLIT in between) would read three-plane rows as two-plane rows; poison the result instead
+  if (ws_stride > 1 && wscale[(int64_t)lat * ws_stride + VD_W_TAG] != (float)S::NPL) ws = __builtin_nanf("");
   b3_combine<S>(acc0, acc1, 1.0f / (ws * ws));
   const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
   const int ib = ibm + half;
@@ -405,7 +409,7 @@ __global__ void k_w_scale(const float *__restrict__ eig_lo, float *__restrict__ 
 template <typename T, class S>
 int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, const T *alpha, const T *X, int n,
                    int d, const T *ell, const T *oscale, double *grad, T *Kinv, int64_t ldk, int64_t strideK,
-                   T *kinv_diag, void *partials, int q, const float *eig_lo, void *stream) {
+                   T *kinv_diag, void *partials, int q, const float *eig_lo, void *stream, const float *Vd = nullptr, int64_t lda_vd = 0) {
   PLMC_REQUIRE(kind >= 0 && kind <= 4, "unknown kernel kind");
   PLMC_REQUIRE(W && alpha && X && ell && grad && partials, "null pointer");
   PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0 && ldw % NB == 0 && n <= n_pad && n > n_pad - NB, "n_pad must be plmc_pad(n)");
@@ -428,18 +432,27 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
   bool done = false;
   if constexpr (!std::is_void<S>::value) {
     PLMC_REQUIRE(q <= 1024, "too many latents for one scale launch");
-    char *pb = reinterpret_cast<char *>(partials) + (int64_t)m * m * q * GP * (int64_t)sizeof(double);
-    unsigned short *wp = reinterpret_cast<unsigned short *>(pb);
-    float *wsc = reinterpret_cast<float *>(pb + (int64_t)q * b3_elems<SplitB3>(n_pad, n_pad) * 2);
-    hipLaunchKernelGGL((k_w_scale<S>), dim3(1), dim3(q < 64 ? 64 : ((q + 63) / 64) * 64), 0, st, eig_lo, wsc, q, (int)(n < n_pad));
-    {
+    // the planes of W and the scale of that operand family: the ones the sweep left in its Vd scratch (plmc_kinv_grad_vd_*:
+    // same scheme, since both calls see the same knob and the same eig_lo) -- or split W now, behind the partials
+    const unsigned short *wp = nullptr;
+    const float *wsc = nullptr;
+    int64_t wp_lat = b3_elems<S>(n_pad, n_pad), ws_lat = 1;
+    if (!(Vd && vd_w_planes(Vd, n_pad, lda_vd, &wp, &wp_lat, &wsc, &ws_lat))) {
+      char *pb = reinterpret_cast<char *>(partials) + (int64_t)m * m * q * GP * (int64_t)sizeof(double);
+      unsigned short *wpo = reinterpret_cast<unsigned short *>(pb);
+      float *wsco = reinterpret_cast<float *>(pb + (int64_t)q * b3_elems<SplitB3>(n_pad, n_pad) * 2);
+      hipLaunchKernelGGL((k_w_scale<S>), dim3(1), dim3(q < 64 ? 64 : ((q + 63) / 64) * 64), 0, st, eig_lo, wsco, q, (int)(n < n_pad));
       ProfScope ps(PK_SPLIT, st, 0.0, (double)q * np * np / 2 * (4 + 2 * S::NPL));
-      hipLaunchKernelGGL((k_split_w<S>), dim3(m, m, q), dim3(NTHREADS), 0, st, (const float *)W, n_pad, ldw, strideW, wp, (const float *)wsc);
+      hipLaunchKernelGGL((k_split_w<S>), dim3(m, m, q), dim3(NTHREADS), 0, st, (const float *)W, n_pad, ldw, strideW, wpo, (const float *)wsco);
+      wp = wpo;
+      wsc = wsco;
+      wp_lat = b3_elems<S>(n_pad, n_pad);
+      ws_lat = 1;
     }
     const dim3 gridb(q * kinv_macro_before(m));
 #define PLMC_LAUNCH_KB(DC, SP) \
   hipLaunchKernelGGL((k_kinv_grad_bf3<S, DC, SP>), gridb, dim3(B3_NT), 0, st, kind, n_pad, alpha, X, n, d, ell, oscale, Kinv, ldk, strideK, kinv_diag, \
-                     part, q, plain, (const unsigned short *)wp, (const float *)wsc)
+                     part, q, plain, wp, wsc, wp_lat, ws_lat)
     ProfScope ps(PK_KINV_GRAD, st, q * np * np * np / 3.0, q * (np * np / 2) * sizeof(T));
     if (d <= 4) PLMC_LAUNCH_KB(4, false);
     else if (d <= 8) PLMC_LAUNCH_KB(8, false);
@@ -486,19 +499,25 @@ int64_t plmc_grad_scratch_bytes_for(int64_t n_pad, int q, int elem_bytes) {
   return m * m * (int64_t)q * plmc::GP * (int64_t)sizeof(double) + planes;
 }
 int64_t plmc_grad_scratch_bytes(int64_t n_pad, int q) { return plmc_grad_scratch_bytes_for(n_pad, q, 4); }
+// what plmc_kinv_grad_vd_* needs when the sweep's scratch supplies the planes of W: the per-tile partial sums only
+int64_t plmc_grad_partials_bytes(int64_t n_pad, int q) {
+  const int64_t m = n_pad / plmc::NB;
+  return m * m * (int64_t)q * plmc::GP * (int64_t)sizeof(double);
+}
 static int kinv_grad_f32_any(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW, const float *alpha,
                              const float *X, int n, int d, const float *ell, const float *oscale, double *grad,
                              float *Kinv, int64_t ldk, int64_t strideK, float *kinv_diag, void *partials, int q, const float *eig_lo,
-                             void *stream) {
+                             void *stream, const float *Vd = nullptr) {
   const int split = plmc::knobs().split;
   if (split == 0)
     return plmc::kinv_grad_impl<float, void>(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk, strideK, kinv_diag, partials, q,
                                              nullptr, stream);
+  // Vd: the scratch of the sweep that produced W, whose leading dimension is ldw (W lives in the factor buffer's columns)
   if (split == 2 && eig_lo)
     return plmc::kinv_grad_impl<float, plmc::SplitH2>(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk, strideK, kinv_diag,
-                                                      partials, q, eig_lo, stream);
+                                                      partials, q, eig_lo, stream, Vd, ldw);
   return plmc::kinv_grad_impl<float, plmc::SplitB3>(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk, strideK, kinv_diag,
-                                                    partials, q, nullptr, stream);
+                                                    partials, q, nullptr, stream, Vd, ldw);
 }
 int plmc_kinv_grad_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW, const float *alpha,
                        const float *X, int n, int d, const float *ell, const float *oscale, double *grad,
@@ -511,6 +530,21 @@ int plmc_kinv_grad_ex_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, 
                           float *Kinv, int64_t ldk, int64_t strideK, float *kinv_diag, void *partials, int q,
                           const float *eig_lo, void *stream) {
   return kinv_grad_f32_any(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk, strideK, kinv_diag, partials, q, eig_lo, stream);
+}
+int plmc_kinv_grad_vd_f32(int kind, const float *W, int64_t n_pad, int64_t ldw, int64_t strideW, const float *alpha,
+                          const float *X, int n, int d, const float *ell, const float *oscale, double *grad,
+                          float *Kinv, int64_t ldk, int64_t strideK, float *kinv_diag, void *partials, int q,
+                          const float *eig_lo, const float *Vd, void *stream) {
+  return kinv_grad_f32_any(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk, strideK, kinv_diag, partials, q, eig_lo, stream, Vd);
+}
+int plmc_kinv_grad_vd_f64(int kind, const double *W, int64_t n_pad, int64_t ldw, int64_t strideW, const double *alpha,
+                          const double *X, int n, int d, const double *ell, const double *oscale, double *grad,
+                          double *Kinv, int64_t ldk, int64_t strideK, double *kinv_diag, void *partials, int q,
+                          const double *eig_lo, const double *Vd, void *stream) {
+  (void)eig_lo;
+  (void)Vd;
+  return plmc::kinv_grad_impl<double, void>(kind, W, n_pad, ldw, strideW, alpha, X, n, d, ell, oscale, grad, Kinv, ldk,
+                                            strideK, kinv_diag, partials, q, nullptr, stream);
 }
 int plmc_kinv_grad_f64(int kind, const double *W, int64_t n_pad, int64_t ldw, int64_t strideW, const double *alpha,
                        const double *X, int n, int d, const double *ell, const double *oscale, double *grad,

@@ -49,7 +49,9 @@ class Workspace:
             self.W = self.A[:, :, self.wcol0:self.wcol0 + self.n_pad]
             self.ldw, self.strideW = self.lda, self.strideA
             self.alpha = torch.empty(q, self.n_pad, dtype=dtype, device=device)
-            nbytes = int(L.cdll.plmc_grad_scratch_bytes_for(self.n_pad, q, esz))
+            # per-tile partial sums of the gradient kernel; the 16-bit planes of W it multiplies are left in Vd by the sweep
+            # (plmc_kinv_grad_vd), except with PLMC_SPLIT=0 / fp64, which need none
+            nbytes = int(L.cdll.plmc_grad_partials_bytes(self.n_pad, q))
             self.partials = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
 
 
@@ -274,9 +276,9 @@ class ExactLatentLogProb(torch.autograd.Function):
                            _hip.ptr(ws.alpha), _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad), None,
                            _hip.ptr(ws.partials), q, gst)
                 else:
-                    L.call("plmc_kinv_grad_ex", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW,
+                    L.call("plmc_kinv_grad_vd", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW,
                            _hip.ptr(ws.alpha), _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad),
-                           None, 0, 0, None, _hip.ptr(ws.partials), q, _hip.ptr(noise_eff), gst)
+                           None, 0, 0, None, _hip.ptr(ws.partials), q, _hip.ptr(noise_eff), _hip.ptr(ws.Vd), gst)
                 if gs is not None:
                     ws.pending = torch.cuda.Event()
                     ws.pending.record(gs)
@@ -412,9 +414,9 @@ def exact_loo(kind, X, ell, oscale, noise, y):
            _hip.ptr(ws.alpha), q, st)
     grad = torch.empty(q, d + 2, dtype=torch.float64, device=dev)
     kd = torch.empty(q, ws.n_pad, dtype=dt, device=dev)
-    L.call("plmc_kinv_grad_ex", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.alpha),
+    L.call("plmc_kinv_grad_vd", dt, _hip.KIND[kind], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.alpha),
            _hip.ptr(Xc), n, d, _hip.ptr(ellc), _hip.ptr(osc), _hip.ptr(grad), None, 0, 0, _hip.ptr(kd),
-           _hip.ptr(ws.partials), q, _hip.ptr(nzc), st)
+           _hip.ptr(ws.partials), q, _hip.ptr(nzc), _hip.ptr(ws.Vd), st)
     sigma2 = 1.0 / kd[:, :n]
     return sigma2, ws.alpha[:, :n] * sigma2
 

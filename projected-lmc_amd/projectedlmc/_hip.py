@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PLMC_LIB: dev override (a variant build of the same library, tools/wb_race_probe.py); never a fallback
 LIB_PATH = os.environ.get("PLMC_LIB") or os.path.join(_HERE, "libplmc_hip.so")
 
-ABI_VERSION = 3          # include/plmc.h: plmc_version()
+ABI_VERSION = 4          # include/plmc.h: plmc_version()
 KIND = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3, "spline": 4}
 
 _c = ctypes
@@ -35,6 +35,7 @@ _TYPED = {
     "plmc_gemm_tn": [_I, _I, _I, _I, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _P],
     "plmc_kinv_grad": [_I, _P, _L, _L, _L, _P, _P, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P],
     "plmc_kinv_grad_ex": [_I, _P, _L, _L, _L, _P, _P, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P, _P],
+    "plmc_kinv_grad_vd": [_I, _P, _L, _L, _L, _P, _P, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P, _P, _P],
     "plmc_grad_tiles": [_I, _P, _L, _L, _L, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     "plmc_lmc_assemble": [_I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P],
     "plmc_lmc_cross": [_I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _P],
@@ -55,6 +56,7 @@ _PLAIN = {
     "plmc_last_error": ([], _c.c_char_p),
     "plmc_grad_scratch_bytes": ([_L, _I], _L),
     "plmc_grad_scratch_bytes_for": ([_L, _I, _I], _L),
+    "plmc_grad_partials_bytes": ([_L, _I], _L),
     "plmc_lmc_grad_len": ([_I, _I, _I], _L),
     "plmc_lmc_grad_scratch_bytes": ([_L, _I, _I, _I], _L),
     "plmc_prof_enable": ([_I], _I),

@@ -141,7 +141,7 @@ def test_c_abi_exports_every_declared_symbol(repo_root):
     lib = ctypes.CDLL(_hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.plmc_block() == 128 and lib.plmc_version() == _hip.ABI_VERSION == 3
+    assert lib.plmc_block() == 128 and lib.plmc_version() == _hip.ABI_VERSION == 4
     lib.plmc_pad.restype, lib.plmc_pad.argtypes = ctypes.c_int64, [ctypes.c_int64]
     assert lib.plmc_pad(1) == 128 and lib.plmc_pad(128) == 128 and lib.plmc_pad(8193) == 8320
 

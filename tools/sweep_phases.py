@@ -33,16 +33,17 @@ def span(d, key, s, e):
     else:
         d[key] = [s, e]
 # bulk kernels: attribute to groups in order of appearance per class
-cls_of = lambda n: ("gp_head" if n.startswith("k_gpanel_rows<float, 1") or n.startswith("k_gpanel_rows<double, 1") else
+chainq = next((q for name, s, e, q in ev if name.startswith("k_diag")), None)       # the chain's queue: the head panel runs there
+cls_of = lambda n, q=None: ("gp_head" if n.startswith("k_gpanel_rows<float, 1") or n.startswith("k_gpanel_rows<double, 1") or (n.startswith("k_gpanel_bf3") and q == chainq) else
                     "gp_rest" if n.startswith("k_gpanel_rows") or n.startswith("k_gpanel_bf3") else
-                    "U1" if n.startswith("k_update<float, 2") or n.startswith("k_update<double, 2") else
+                    "U1" if n.startswith("k_update<float, 2") or n.startswith("k_update<double, 2") or (n.startswith("k_update_bf3<") and n.endswith(" 2>")) else
                     "head" if (n.startswith("k_update_bf3<") and n.endswith(" 3>")) or n.startswith("k_update<float, 3") or n.startswith("k_update<double, 3") else
                     "tail" if (n.startswith("k_update_bf3<") and n.endswith(" 0>")) or n.startswith("k_update<float, 0") or n.startswith("k_update<double, 0") else None)
 cnt = {}
 split_on = any("_bf3<" in name for name, *_ in ev)      # split engine: its launches define the phases; the fp32 launches of the
 for name, s, e, q in ev:                                 # same class only carry the augmented columns
-    c = cls_of(name)
-    if split_on and c in ("gp_rest", "head", "tail") and "_bf3<" not in name:
+    c = cls_of(name, q)
+    if split_on and c in ("gp_head", "gp_rest", "U1", "head", "tail") and "_bf3<" not in name:
         continue
     if c is None:
         continue
