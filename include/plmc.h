@@ -340,11 +340,13 @@ int plmc_qr_small_f64(const double *A, int m, int n, int64_t lda, double *Q, int
  * events, then returns per kernel class (index < plmc_prof_kernels(), name plmc_prof_name(i)):
  * total milliseconds, number of launches, and the ALGORITHMIC flops / bytes of those launches;
  * it clears the record.
- * Process-global state of the library (all of it): this profiler record; per device, two helper streams and nine
- * ordering events of the look-ahead in plmc_potrf_* (created on first use, never destroyed) and the caller stream of the
- * last sweep.  A sweep on the SAME device from ANOTHER caller stream waits (stream-side, an event) for the previous one;
- * calls from several host THREADS on one device must not overlap (they would share the streams, the events and this
- * bookkeeping); different devices are independent.  The Python layer calls from one thread per process.
+ * Process-global state of the library (all of it): this profiler record; per device, TWO sets of three helper streams and
+ * sixteen ordering events for the look-ahead in plmc_potrf_* (created on first use, never destroyed), each bound to the
+ * caller stream that used it last.  Sweeps queued on one stream share a set (stream order protects it); sweeps from two
+ * streams get a set each and may overlap on the device (their buffers must differ); a third stream takes over the least
+ * recently used set and waits (stream-side, an event) for that set's last sweep.  Calls from several host THREADS on one
+ * device must not overlap (they would race on this bookkeeping); different devices are independent.  The Python layer
+ * calls from one thread per process.
  * Dev knobs are environment variables read once per process (PLMC_HALF_TILES, PLMC_GRP, PLMC_KINV_ORDER,
  * PLMC_SERIAL, PLMC_BULK_LDS); plmc_dev_reload_knobs() re-reads them (tests and bench.py change one and reload).  They change
  * schedules; PLMC_GRP also changes the depth of the updates and with it the rounding.  PLMC_SPLIT (0, 2, 3) selects the

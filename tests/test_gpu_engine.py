@@ -132,6 +132,52 @@ def test_split_engines_against_fp32_mfma_path(eng, n, d, q, monkeypatch):
             assert e_split < 2.0 * e_plain + 2e-6, (e_split, e_plain)
 
 
+@pytest.mark.parametrize("n,q", [(900, 2), (2500, 3)])
+def test_kinv_grad_from_the_sweeps_planes_equals_the_split_pass(eng, n, q):
+    """plmc_kinv_grad_vd_* multiplies the planes of W the sweep left in its Vd scratch; plmc_kinv_grad_ex_* splits W again
+    into its own scratch.  Same fp32 values, same power-of-two scale, same kernel: the gradients must be IDENTICAL (one group
+    of block rows: inverse triangle only; three groups: group panels too).  A sweep without eigenvalue bounds (three bf16
+    planes) followed by a K^-1 call with them (two fp16 planes) must not go unnoticed: the scratch records its scheme and the
+    mismatch poisons the gradients."""
+    from projectedlmc import _hip
+    L = _hip.lib()
+    d, dt, dev = 5, torch.float32, torch.device("cuda:0")
+    X, y, ell, noise, osc = _problem(n, d, q, seed=n)
+    f = lambda t: t.to(dev, dt).contiguous()
+    Xd, yd, elld, nzd = f(X), f(y), f(ell), f(noise)
+    ws = eng.Workspace(n, q, 1, dt, dev, True)
+    st = _hip.stream_ptr(dev)
+
+    def grads(entry, with_bounds_in_sweep=True, **kw):
+        L.call("plmc_assemble", dt, _hip.KIND["matern52"], _hip.ptr(Xd), n, d, _hip.ptr(elld), None, _hip.ptr(nzd), _hip.ptr(ws.A), ws.lda, ws.strideA, q, st)
+        L.call("plmc_write_rhs", dt, _hip.ptr(yd), 1, n, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, ws.naug_pad, q, st)
+        L.call("plmc_potrf_ex", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.naug, ws.strideA, _hip.ptr(ws.Vd), _hip.ptr(ws.logdet), _hip.ptr(ws.info), 1, q,
+               _hip.ptr(nzd) if with_bounds_in_sweep else None, st)
+        L.call("plmc_extract_col", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, 0, _hip.ptr(ws.z), _hip.ptr(ws.quad), q, st)
+        L.call("plmc_wt_matvec", dt, _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.z), _hip.ptr(ws.alpha), q, st)
+        g = torch.zeros(q, d + 2, dtype=torch.float64, device=dev)
+        kd = torch.zeros(q, ws.n_pad, dtype=dt, device=dev)
+        if entry == "vd":
+            part = torch.empty(int(L.cdll.plmc_grad_partials_bytes(ws.n_pad, q)) // 8, dtype=torch.float64, device=dev)
+            L.call("plmc_kinv_grad_vd", dt, _hip.KIND["matern52"], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.alpha), _hip.ptr(Xd), n, d,
+                   _hip.ptr(elld), None, _hip.ptr(g), None, 0, 0, _hip.ptr(kd), _hip.ptr(part), q, _hip.ptr(nzd), _hip.ptr(ws.Vd), st)
+        else:
+            part = torch.empty(int(L.cdll.plmc_grad_scratch_bytes_for(ws.n_pad, q, 4)) // 8, dtype=torch.float64, device=dev)
+            L.call("plmc_kinv_grad_ex", dt, _hip.KIND["matern52"], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.alpha), _hip.ptr(Xd), n, d,
+                   _hip.ptr(elld), None, _hip.ptr(g), None, 0, 0, _hip.ptr(kd), _hip.ptr(part), q, _hip.ptr(nzd), st)
+        torch.cuda.synchronize()
+        return g.cpu(), kd.cpu()
+
+    for knob in ("2", "3"):
+        with _hip.knob("PLMC_SPLIT", knob):
+            g_vd, kd_vd = grads("vd")
+            g_ex, kd_ex = grads("ex")
+        assert torch.isfinite(g_vd).all() and g_vd.abs().max() > 0
+        assert torch.equal(g_vd, g_ex) and torch.equal(kd_vd, kd_ex), (knob, (g_vd - g_ex).abs().max())
+    g_bad, _ = grads("vd", with_bounds_in_sweep=False)        # three-plane sweep, two-plane K^-1 call
+    assert torch.isnan(g_bad).all()
+
+
 def test_fp16_split_handles_extreme_scales(eng):
     """The two-plane fp16 split scales its operands by bounds derived from the largest diagonal entry and the noise, so that
     fp16 never overflows and small magnitudes keep their bits: tiny noise (W entries ~ 1 / sqrt(noise) large), large and
