@@ -253,6 +253,43 @@ def _schedule_independence_body(eng, n, q, dtype):
     torch.cuda.empty_cache()
 
 
+def test_sweeps_from_three_caller_streams_overlap_safely(eng):
+    """The helper streams and ordering events of the look-ahead are bound to the CALLER stream (two sets per device, api.hip):
+    sweeps queued on two streams at once (own buffers) run concurrently on their own sets, a third stream takes over the least
+    recently used set and must first wait for that set's last sweep.  All three factor buffers must equal, bit for bit, what
+    the same sweeps give one after the other on one stream."""
+    n, q, d, dtype = 4096, 2, 6, torch.float32
+    g = torch.Generator().manual_seed(11)
+    X = (2 * torch.rand(n, d, generator=g, dtype=dtype) - 1).to(DEV)
+    it = torch.int32
+    probs = []
+    for k in range(3):
+        y = torch.randn(q, n, generator=g, dtype=dtype).to(DEV)
+        ell = (0.4 + 0.2 * k + 0.3 * torch.rand(q, d, generator=g, dtype=dtype)).to(DEV)
+        noise = (0.05 + 0.1 * k + 0.2 * torch.rand(q, generator=g, dtype=dtype)).to(DEV)
+        probs.append((ell, noise, y.reshape(q, 1, n).contiguous(), eng.Workspace(n, q, 1, dtype, torch.device(DEV), True)))
+    torch.cuda.synchronize()
+    ref = []
+    for ell, noise, y, ws in probs:                              # one after the other, one stream
+        eng.factorize("matern52", X, ell, None, noise, y, ws)
+        torch.cuda.synchronize()
+        ref.append((ws.A.view(it).clone(), ws.logdet.clone()))
+        ws.A.zero_()
+    streams = [torch.cuda.Stream(DEV) for _ in probs]
+    for rep in range(3):
+        torch.cuda.synchronize()
+        for (ell, noise, y, ws), s in zip(probs, streams):       # all three in flight together
+            with torch.cuda.stream(s):
+                eng.factorize("matern52", X, ell, None, noise, y, ws)
+        torch.cuda.synchronize()
+        for k, ((ell, noise, y, ws), (A_ref, ld_ref)) in enumerate(zip(probs, ref)):
+            ndiff = int((ws.A.view(it) != A_ref).sum())
+            assert ndiff == 0, "round %d, stream %d: %d elements differ from the sequential sweep" % (rep, k, ndiff)
+            assert torch.equal(ws.logdet, ld_ref)
+    del probs, ref
+    torch.cuda.empty_cache()
+
+
 def test_training_step_is_deterministic_at_metric_shape(eng):
     """Whole MLL + gradient evaluation (sweep, alpha, fused K^-1 + gradient kernel on its own stream) repeated at the
     metric shape: log-probs and every gradient bit-identical."""
