@@ -179,7 +179,7 @@ __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad
 // The same on the bf16 matrix cores (fp32 only; bf3_engine.hpp): a workgroup of 512 threads takes the macro tile
 // (ib, ib + 1) x jb of K^-1 = W^T W from the k8-ordered planes of W (`Wp`, written by k_split_w; per latent
 // b3_elems(n_pad, n_pad) 16-bit elements), then each half of 256 threads runs the gradient epilogue on its own tile.
-// Order: longest K range first (jb ascending), latent fastest; macro tiles of column jb: ib = 0, 2, .. <= jb.
+// Order: latent by latent, within a latent longest K range first (jb ascending); macro tiles of column jb: ib = 0, 2, .. <= jb.
 // number of macro tiles in block columns < j:  j even: (j/2)^2 + j/2,  j odd: ((j+1)/2)^2
 __host__ __device__ inline int kinv_macro_before(int j) { const int a = j >> 1; return (j & 1) ? (a + 1) * (a + 1) : a * a + a; }
 // `wscale`: per latent the power-of-two scale the planes of W were written with (SplitH2; SplitB3: ones).
@@ -192,7 +192,11 @@ __global__ __launch_bounds__(B3_NT, 2) void k_kinv_grad_bf3(int kind, int64_t n_
   constexpr int LDS_BYTES = b3_lds_bytes<S>() > 2 * tile_smem_elems<float>() * (int)sizeof(float) ? b3_lds_bytes<S>() : 2 * tile_smem_elems<float>() * (int)sizeof(float);
   __shared__ __align__(16) unsigned char lds[LDS_BYTES];
   const int m = (int)(n_pad / NB);
-  const int w = blockIdx.x, lat = w % nlat, t = w / nlat;
+  // latent-major: the ~256 resident workgroups are consecutive macro tiles of ONE matrix (a few block columns jb, all their
+  // ibm): 16 + 16 operand strips instead of one B and 32 A strips per XCD and latent -- the strips are shared across the XCDs
+  // through the Infinity Cache (step 18.5 -> 18.1 ms at q = 8; PLMC_KINV_ORDER=7: latent fastest, the fp32 kernel's order)
+  const int ntile = kinv_macro_before(m);
+  const int w = blockIdx.x, lat = plain == 7 ? w % nlat : w / ntile, t = plain == 7 ? w / nlat : w % ntile;
   int jb = (int)(2.0f * sqrtf((float)t));
   if (jb >= m) jb = m - 1;
   while (jb + 1 < m && kinv_macro_before(jb + 1) <= t) ++jb;
