@@ -294,12 +294,23 @@ template <class S> __device__ __forceinline__ void b3_combine(Acc<float> &acc0, 
 // 8 rows x 4 columns.  `live`: a half without a tile takes part in the barriers only (its descriptor has zero records: loads
 // give 0, stores are dropped); `planes_live`: this half also writes planes (both wave-uniform per half).
 constexpr int B3_WB_NCH = 8;
+// Cache policy of the C tile's loads and stores: nt (aux = 2).  A C tile is touched once per launch and streams through
+// (208 MB per latent in the tail of the metric shape, 16 GB at n = 44 484); with the default policy it pushes the operand
+// planes -- which every macro row re-reads -- out of the Infinity Cache.  Measured (variant builds, -DB3_C_AUX / -DB3_C_AUX_ST):
+// loads and stores nt together 18.07 -> 17.87 ms/step at the metric shape, 304 -> 291 ms at the C5 share; either one alone: no
+// gain.  The planes' own stores keep the default policy (they are the next launch's operands).
+#ifndef B3_C_AUX
+#define B3_C_AUX 2
+#endif
+#ifndef B3_C_AUX_ST
+#define B3_C_AUX_ST 2
+#endif
 __device__ __forceinline__ void b3_preload(f32x4 (&vc)[B3_WB_NCH], const float *Cg, int64_t ldc, int tid, bool live) {
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Cg), 0, __builtin_amdgcn_readfirstlane(live ? 0x7fffffff : 0), 0x00020000);
   const unsigned voff = (unsigned)(((int64_t)(tid / 32) * ldc + (tid % 32) * 4) * 4);
   const unsigned rstep = (unsigned)((int64_t)8 * ldc * 4);
 #pragma unroll
-  for (int h = 0; h < B3_WB_NCH; ++h) vc[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rC, voff, (unsigned)h * rstep, 0));
+  for (int h = 0; h < B3_WB_NCH; ++h) vc[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rC, voff, (unsigned)h * rstep, B3_C_AUX));
 }
 template <class S, int MODE, bool PLANES, bool PRE = false>
 __device__ __forceinline__ void b3_writeback(const Acc<float> &acc, float *Cg, int64_t ldc, float *smem, int tid, bool live,
@@ -317,9 +328,9 @@ __device__ __forceinline__ void b3_writeback(const Acc<float> &acc, float *Cg, i
   if (ADD) {
 #pragma unroll
     for (int h = 0; h < NCH; ++h)
-      vc[0][h] = PRE ? vc0[h] : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rC, voff, (unsigned)h * rstep, 0));
+      vc[0][h] = PRE ? vc0[h] : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rC, voff, (unsigned)h * rstep, B3_C_AUX));
 #pragma unroll
-    for (int h = 0; h < NCH; ++h) vc[1][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rC, voff, (unsigned)(8 + h) * rstep, 0));
+    for (int h = 0; h < NCH; ++h) vc[1][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rC, voff, (unsigned)(8 + h) * rstep, B3_C_AUX));
   }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -342,7 +353,7 @@ __device__ __forceinline__ void b3_writeback(const Acc<float> &acc, float *Cg, i
       const f32x4 o = MODE == WB_ADD ? vc[half][h] + sv : (MODE == WB_SUB ? vc[half][h] - sv : (MODE == WB_STORE_NEG ? -sv : sv));
       if (PLANES && MODE != WB_STORE) *reinterpret_cast<f32x4 *>(sp) = o;   // each thread owns its chunks: the staging area now holds the finals
       // row-chunk offset in voffset, soffset = 0: the store-data hazard note of gemm_core.hpp
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o), rC, voff + (unsigned)(half * 8 + h) * rstep, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o), rC, voff + (unsigned)(half * 8 + h) * rstep, 0, B3_C_AUX_ST);
     }
     if constexpr (PLANES) {
       __syncthreads();
