@@ -137,7 +137,9 @@ __device__ __forceinline__ void b3_split_block(const float *__restrict__ Sp, int
 // operations of the wave, so the remaining barriers wait for "all but the NPRE youngest" and the loads stay in flight
 // through the last two stages (an older load would hold back every DMA piece behind it: vmcnt counts in issue order).
 struct B3NoPre { __device__ __forceinline__ void operator()() const {} };
-template <class S, int NSTG = 2, int NPRE = 0, class PRE = B3NoPre>
+// REV: walk the K range from its last stage to its first -- tiles whose ranges END at the same row (the K^-1 tiles: every
+// range ends at n) then read the same operand rows at the same time, whatever their length.
+template <class S, int NSTG = 2, int NPRE = 0, class PRE = B3NoPre, bool REV = false>
 __device__ __forceinline__ void b3_mainloop(Acc<float> &acc0, Acc<float> &acc1, const unsigned short *__restrict__ Ap, int64_t lda_,
                                             const unsigned short *__restrict__ Bp, int64_t ldb_, int K, unsigned char *lds, PRE pre = PRE()) {
   static_assert(NPRE == 0 || (NPRE == 8 && NSTG == 2), "pre-loads: eight, two-stage loop only");
@@ -156,8 +158,10 @@ __device__ __forceinline__ void b3_mainloop(Acc<float> &acc0, Acc<float> &acc1, 
   const unsigned lA0 = (unsigned)(((w >> 2) * B3_AW + (w & 3) * 64) * 16);
   const unsigned lB0 = (unsigned)(NPL * B3_A_PLANE + (((w >> 1) & 3) * B3_BW + (w & 1) * 64) * 16);
   const unsigned voff = (unsigned)lane * 16u;
-  const char *baseA = reinterpret_cast<const char *>(Ap), *baseB = reinterpret_cast<const char *>(Bp);
-  const int64_t stepA = (int64_t)(B3_K / 8) * RSA, stepB = (int64_t)(B3_K / 8) * RSB;
+  const int64_t fwdA = (int64_t)(B3_K / 8) * RSA, fwdB = (int64_t)(B3_K / 8) * RSB;
+  const int64_t stepA = REV ? -fwdA : fwdA, stepB = REV ? -fwdB : fwdB;
+  const char *baseA = reinterpret_cast<const char *>(Ap) + (REV ? (int64_t)(K / B3_K - 1) * fwdA : 0);
+  const char *baseB = reinterpret_cast<const char *>(Bp) + (REV ? (int64_t)(K / B3_K - 1) * fwdB : 0);
   typedef __attribute__((address_space(3))) void lds_void;
   auto issue = [&](int buf) {
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(baseA), 0, 0x7fffffff, 0x00020000);

@@ -747,8 +747,12 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const int64_t pl_buf = b3_elems<SplitB3>((int64_t)GMAX * NB, lda);    // 16-bit elements reserved per group of rows
   unsigned short *const Pl0 = bf3 ? reinterpret_cast<unsigned short *>(Pbulk + (int64_t)GMAX * NB * lda) : nullptr;
   unsigned short *const Praw = bf3 ? Pl0 + 2 * pl_buf : nullptr;         // raw rows of the group whose panel comes next (one group)
-  unsigned short *const VgP = bf3 ? Praw + pl_buf : nullptr;             // planes of Vgg: 128 GMAX x 128 GMAX
-  float *const scl = bf3 ? reinterpret_cast<float *>(VgP + b3_elems<SplitB3>((int64_t)GMAX * NB, (int64_t)GMAX * NB)) : nullptr;   // SC_N floats
+  // planes of Vgg (128 GMAX x 128 GMAX), ping-pong like Vg2: the rest panel of group gi (helper stream H) may still read its
+  // copy while the chain stream transposes the triangle of group gi + 1 (nothing orders those two; with one copy a delayed
+  // rest panel -- other sweeps in flight on the device -- read half-overwritten planes)
+  const int64_t vgp_elems = b3_elems<SplitB3>((int64_t)GMAX * NB, (int64_t)GMAX * NB);
+  unsigned short *const VgP2[2] = {bf3 ? Praw + pl_buf : nullptr, bf3 ? Praw + pl_buf + vgp_elems : nullptr};
+  float *const scl = bf3 ? reinterpret_cast<float *>(VgP2[1] + vgp_elems) : nullptr;   // SC_N floats
   // ... and, with the inverse factor, the full-height planes of W (n_pad columns per plane row) that plmc_kinv_grad_vd_* reads:
   // written by the same epilogues that write the rolling buffer, so the K^-1 kernel needs no split pass over W
   unsigned short *const Wk = (bf3 && with_inverse && vd_wk_blocks(n_pad, lda, (int)sizeof(T)) > 0)
@@ -895,8 +899,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       const int nb_ = cb.nU + cb.Taug + cb.nW, nm = (G + 1) / 2;
       if (nb_ > 0)
         hipLaunchKernelGGL((k_gpanel_bf3<SS>), dim3(nb_, head ? nm : (nm + 1) / 2, q), dim3(B3_NT), 0, s, A, lda, strideA, g0, G, cb,
-                           (const unsigned short *)VgP, pl_lat, (const unsigned short *)Praw, pl_lat, planes(g0), pl_lat, wcol0, (const float *)scl, sc_lat,
-                           head ? 0 : 1, Wk, pl_lat);
+                           (const unsigned short *)VgP2[Vg == Vg2[1]], pl_lat, (const unsigned short *)Praw, pl_lat, planes(g0), pl_lat, wcol0,
+                           (const float *)scl, sc_lat, head ? 0 : 1, Wk, pl_lat);
       if (aug_fp32) fp32_panel(ca);
       return;
     }
@@ -962,7 +966,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     T *wo = WA ? WA + (int64_t)g0 * NB * lda + (int64_t)g0 * NB : (T *)nullptr;
     // (split engine: also the planes of Vgg, zero blocks included -- one workgroup per block of the GMAX x GMAX grid)
     hipLaunchKernelGGL((k_vtrans<T, S>), dim3(bf3 ? GMAX * GMAX : G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)Wg, (int64_t)LDG, strideV,
-                       strideV, Vg2[gi & 1], G, wo, lda, strideA, VgP, pl_lat, (const float *)scl, sc_lat);
+                       strideV, Vg2[gi & 1], G, wo, lda, strideA, VgP2[gi & 1], pl_lat, (const float *)scl, sc_lat);
   };
   // PLMC_BF16X3: planes of the group's inverse triangle (read back from the W columns k_vtrans wrote; any stream behind it)
   auto wtri_planes = [&](int gi, hipStream_t s) {
@@ -1117,7 +1121,7 @@ bool vd_w_planes(const float *Vd, int64_t n_pad, int64_t lda, const unsigned sho
   const int64_t pl_buf = b3_elems<SplitB3>((int64_t)GMAX * NB, lda);
   const unsigned short *Pl0 = reinterpret_cast<const unsigned short *>(Pbulk + (int64_t)GMAX * NB * lda);
   const unsigned short *VgP = Pl0 + 3 * pl_buf;
-  const float *scl = reinterpret_cast<const float *>(VgP + b3_elems<SplitB3>((int64_t)GMAX * NB, (int64_t)GMAX * NB));
+  const float *scl = reinterpret_cast<const float *>(VgP + 2 * b3_elems<SplitB3>((int64_t)GMAX * NB, (int64_t)GMAX * NB));
   *wk = reinterpret_cast<const unsigned short *>(scl + (int64_t)NB * NB);
   *wk_lat_stride = strideV * 2;
   *w_scale = scl + SC_SW;                                        // (the scheme tag sits SC_TAG - SC_SW floats behind it)
@@ -1209,9 +1213,9 @@ int64_t plmc_vd_blocks_for(int64_t n_pad, int64_t lda, int elem_bytes) {
   const int64_t ldb = (lda + plmc::NB - 1) / plmc::NB;
   // (version 4) + the full-height planes of W for plmc_kinv_grad_vd_*, when the layout has inverse-factor columns
   // planes (4-byte elements): rolling buffer of the solved panel rows (2 groups) + raw rows of the next group (1 group), each
-  // 128 GMAX rows x 3 planes x lda x 2 bytes = 12 ldb blocks at GMAX = 8, + Vgg (3 x (128 GMAX)^2 x 2 bytes = 96 blocks)
+  // 128 GMAX rows x 3 planes x lda x 2 bytes = 12 ldb blocks at GMAX = 8, + two copies of Vgg (3 x (128 GMAX)^2 x 2 bytes = 96 blocks each)
   // + 1 block holding the scales of the operand families
-  const int64_t planes = elem_bytes == 4 ? 3 * (3 * plmc::GMAX * ldb / 2) + 6 * plmc::GMAX * plmc::GMAX / 4 + 1 : 0;
+  const int64_t planes = elem_bytes == 4 ? 3 * (3 * plmc::GMAX * ldb / 2) + 2 * (6 * plmc::GMAX * plmc::GMAX / 4) + 1 : 0;
   return 2 * (n_pad / plmc::NB) + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ldb + planes + plmc::vd_wk_blocks(n_pad, lda, elem_bytes);
 }
 int64_t plmc_vd_blocks(int64_t n_pad, int64_t lda) { return plmc_vd_blocks_for(n_pad, lda, 4); }

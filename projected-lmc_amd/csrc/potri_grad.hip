@@ -179,9 +179,6 @@ __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad
 // The same on the bf16 matrix cores (fp32 only; bf3_engine.hpp): a workgroup of 512 threads takes the macro tile
 // (ib, ib + 1) x jb of K^-1 = W^T W from the k8-ordered planes of W (`Wp`, written by k_split_w; per latent
 // b3_elems(n_pad, n_pad) 16-bit elements), then each half of 256 threads runs the gradient epilogue on its own tile.
-// Order: latent by latent, within a latent longest K range first (jb ascending); macro tiles of column jb: ib = 0, 2, .. <= jb.
-// number of macro tiles in block columns < j:  j even: (j/2)^2 + j/2,  j odd: ((j+1)/2)^2
-__host__ __device__ inline int kinv_macro_before(int j) { const int a = j >> 1; return (j & 1) ? (a + 1) * (a + 1) : a * a + a; }
 // `wscale`: per latent the power-of-two scale the planes of W were written with (SplitH2; SplitB3: ones).
 template <class S, int DCAP, bool SPLINE = false>
 __global__ __launch_bounds__(B3_NT, 2) void k_kinv_grad_bf3(int kind, int64_t n_pad, const float *__restrict__ alpha, const float *__restrict__ X, int n,
@@ -195,18 +192,27 @@ __global__ __launch_bounds__(B3_NT, 2) void k_kinv_grad_bf3(int kind, int64_t n_
   // latent-major: the ~256 resident workgroups are consecutive macro tiles of ONE matrix (a few block columns jb, all their
   // ibm): 16 + 16 operand strips instead of one B and 32 A strips per XCD and latent -- the strips are shared across the XCDs
   // through the Infinity Cache (step 18.5 -> 18.1 ms at q = 8; PLMC_KINV_ORDER=7: latent fastest, the fp32 kernel's order)
-  const int ntile = kinv_macro_before(m);
-  const int w = blockIdx.x, lat = plain == 7 ? w % nlat : w / ntile, t = plain == 7 ? w / nlat : w % ntile;
-  int jb = (int)(2.0f * sqrtf((float)t));
-  if (jb >= m) jb = m - 1;
-  while (jb + 1 < m && kinv_macro_before(jb + 1) <= t) ++jb;
-  while (kinv_macro_before(jb) > t) --jb;
-  const int ibm = 2 * (t - kinv_macro_before(jb));
+  // Tile order: XCD-dealt super-blocks of 4 macro rows x 8 block columns (= the 32 workgroups an XCD holds; workgroup w lands on
+  // XCD w % 8), longest K range first, latent by latent.  With the K range walked from its END (every range ends at row n) the
+  // 32 tiles of a block read their 4 A strips and 8 B strips in lockstep through one L2, and the blocks in flight on the eight
+  // XCDs belong to one or two matrices (Infinity Cache).  PMC, q = 8: 12.7 GB fetched per launch; the plain orders (latent
+  // fastest / latent by latent, forward walk) 14.7 / 26.4 GB at 5.1 / 4.7 ms against 4.7 ms here.
+  const int SJ = (m + 7) / 8, NSB = SJ * (SJ + 1) / 2;
+  const int w = blockIdx.x, xcd = w & 7, slot = w >> 3;
+  const int gb = xcd + 8 * (slot >> 5), in = slot & 31;
+  if (gb >= nlat * NSB) return;
+  const int lat = gb / NSB, kb = gb - lat * NSB;
+  int sj = (int)((sqrtf(8.0f * (float)kb + 1.0f) - 1.0f) * 0.5f);
+  while ((sj + 1) * (sj + 2) / 2 <= kb) ++sj;
+  while (sj * (sj + 1) / 2 > kb) --sj;
+  const int sa = kb - sj * (sj + 1) / 2;
+  const int ibm = 2 * (4 * sa + (in >> 3)), jb = 8 * sj + (in & 7);
+  if (jb >= m || ibm > jb) return;
   Acc<float> acc0, acc1;
   acc0.zero();
   acc1.zero();
   const unsigned short *Pl = Wp + (int64_t)lat * wp_lat_stride + b3_index<S>((int64_t)jb * NB, 0, 0, n_pad);
-  b3_mainloop<S>(acc0, acc1, Pl + (int64_t)ibm * NB * 8, n_pad, Pl + (int64_t)jb * NB * 8, n_pad, (int)(n_pad - (int64_t)jb * NB), lds);
+  b3_mainloop<S, 2, 0, B3NoPre, true>(acc0, acc1, Pl + (int64_t)ibm * NB * 8, n_pad, Pl + (int64_t)jb * NB * 8, n_pad, (int)(n_pad - (int64_t)jb * NB), lds);
   float ws = wscale[(int64_t)lat * ws_stride];
   // planes taken over from a sweep (ws_stride > 1): they must be of THIS scheme -- a sweep without eig_lo followed by a K^-1 call
   // with it (or a changed PLMC_SPLIT in between) would read three-plane rows as two-plane rows; poison the result instead
@@ -453,7 +459,8 @@ int kinv_grad_impl(int kind, const T *W, int64_t n_pad, int64_t ldw, int64_t str
       wp_lat = b3_elems<S>(n_pad, n_pad);
       ws_lat = 1;
     }
-    const dim3 gridb(q * kinv_macro_before(m));
+    const int SJ = (m + 7) / 8, NSB = SJ * (SJ + 1) / 2;
+    const dim3 gridb(8 * ((q * NSB + 7) / 8) * 32);                       // XCD-dealt super-blocks of 32 macro tiles (see the kernel)
 #define PLMC_LAUNCH_KB(DC, SP) \
   hipLaunchKernelGGL((k_kinv_grad_bf3<S, DC, SP>), gridb, dim3(B3_NT), 0, st, kind, n_pad, alpha, X, n, d, ell, oscale, Kinv, ldk, strideK, kinv_diag, \
                      part, q, plain, wp, wsc, wp_lat, ws_lat)

@@ -1,24 +1,40 @@
-"""Dev aid: every kernel of one whole training step (assemble of step k to assemble of step k+1) from a rocprofv3
-kernel-trace CSV, in start order: offset, duration, queue, name.  Runs of sweep kernels are folded into one line."""
+"""Dev aid: one whole training step (from one k_assemble to the next) out of a rocprofv3 kernel-trace CSV: what runs outside the
+library's kernels (torch: projection, loss terms, optimiser), where, and how long the GPU idles between kernels.
+    python tools/step_timeline.py <kernel_trace.csv> [verbose]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 asm = [i for i, r in enumerate(rows) if "k_assemble" in r["Kernel_Name"]]
 a, b = asm[-2], asm[-1]
-t0 = int(rows[a]["Start_Timestamp"])
-sweep = ("k_diag", "k_panel", "k_update", "k_gpanel", "k_vtrans", "k_zero_diag")
-fold = None
-def flush():
-    global fold
-    if fold:
-        print("%9.1f %9.1f  q=%-3s [%d sweep kernels, last ends %.1f]" % (fold[0], fold[1] - fold[0], "*", fold[2], fold[1]))
-    fold = None
-for r in rows[a:b + 1]:
-    s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
-    nm = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("plmc::", "")
-    if any(k in nm for k in sweep):
-        fold = [s, e, 1] if not fold else [fold[0], max(fold[1], e), fold[2] + 1]
-        continue
-    flush()
-    print("%9.1f %9.1f  q=%-3s %s" % (s, e - s, r.get("Queue_Id", "?"), nm[:90]))
-flush()
+win = rows[a:b]
+t0 = int(win[0]["Start_Timestamp"])
+T = (int(rows[b]["Start_Timestamp"]) - t0) / 1e3
+nm = lambda r: r["Kernel_Name"].split("(")[0].replace("void ", "").replace("plmc::", "")[:60]
+is_lib = lambda r: "plmc" in r["Kernel_Name"]
+lib = [r for r in win if is_lib(r)]
+oth = [r for r in win if not is_lib(r)]
+lib_end = max(int(r["End_Timestamp"]) for r in lib)
+sweep_end = max(int(r["End_Timestamp"]) for r in lib if "k_logdet" in r["Kernel_Name"] or "k_update" in r["Kernel_Name"] or "k_gpanel" in r["Kernel_Name"])
+print("step period %.1f us: %d library kernels, %d other kernels" % (T, len(lib), len(oth)))
+print("  library kernels span 0 .. %.1f us (sweep ends %.1f)" % ((lib_end - t0) / 1e3, (sweep_end - t0) / 1e3))
+# union busy / idle over the period
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in win)
+busy, cs, ce, gaps = 0, iv[0][0], iv[0][1], []
+for s, e in iv[1:]:
+    if s > ce:
+        busy += ce - cs; gaps.append(((cs if False else ce) - t0, s - ce)); cs, ce = s, e
+    else:
+        ce = max(ce, e)
+busy += ce - cs
+print("  GPU busy %.1f us, idle %.1f us in %d gaps" % (busy / 1e3, T - busy / 1e3, len(gaps) + 1))
+big = sorted(gaps, key=lambda g: -g[1])[:8]
+print("  largest gaps (at us: length us):", ", ".join("%.0f: %.0f" % (g[0] / 1e3, g[1] / 1e3) for g in sorted(big)))
+after = [r for r in oth if int(r["Start_Timestamp"]) >= lib_end]
+during = [r for r in oth if int(r["Start_Timestamp"]) < lib_end]
+print("  other kernels while library kernels run: %d (%.1f us of kernel time); after the last library kernel: %d (%.1f us of kernel time, wall %.1f us)" % (
+    len(during), sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in during) / 1e3, len(after),
+    sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in after) / 1e3, T - (lib_end - t0) / 1e3))
+if len(sys.argv) > 2:
+    for r in win:
+        if not is_lib(r) or any(k in r["Kernel_Name"] for k in ("k_assemble", "k_logdet", "k_kinv", "k_wt_matvec", "k_extract", "k_reduce", "k_qr", "k_write_rhs")):
+            print("%9.1f %7.1f q%-2s %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Queue_Id", "?"), nm(r)))
