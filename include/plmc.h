@@ -263,6 +263,24 @@ int plmc_kinv_grad_vd_f64(int kind, const double *W, int64_t n_pad, int64_t ldw,
                           double *kinv_diag, void *partials, int q, const double *eig_lo, const double *Vd, void *stream);
 
 /*
+ * The one exchange of the sharded path, for a host without torch.distributed (the Python layer's default
+ * is torch.distributed "nccl" = RCCL, `projectedlmc/parallel.py`, which can be switched to these with PLMC_COMM=rccl):
+ * a direct RCCL all-reduce (sum, in place) of the fused [loss share | parameter gradients] buffer after backward
+ * (experiments.py:270-272 on every rank) and of the (2, n*, p) partial prediction sums (projected_lmc.py:1144,1152).
+ * RCCL is opened at run time (dlopen; no link-time dependency).  One communicator per process, bound to the device that is
+ * current at plmc_comm_init.  Bootstrap: rank 0 calls plmc_comm_unique_id (128 bytes) and the host's launcher carries the
+ * bytes to the other ranks (environment, file, MPI, a torch.distributed broadcast); then every rank calls plmc_comm_init.
+ * plmc_comm_allreduce_sum_* is asynchronous on `stream`.  Returns 0 or a negative code (plmc_last_error()).
+ */
+int plmc_comm_unique_id(void *id128);
+int plmc_comm_init(const void *id128, int rank, int world);
+int plmc_comm_world(void);                    /* 0 without a communicator */
+int plmc_comm_rank(void);                     /* -1 without a communicator */
+int plmc_comm_allreduce_sum_f32(float *buf, int64_t count, void *stream);
+int plmc_comm_allreduce_sum_f64(double *buf, int64_t count, void *stream);
+int plmc_comm_destroy(void);
+
+/*
  * Exact (dense) LMC / ICM: Kronecker-structured coregionalisation.
  * Replaces `MultitaskGPModel.forward` -> gpytorch LCMKernel / MultitaskKernel (:462-466, :586-589)
  * + MultitaskGaussianLikelihood (experiments.py:184) and their autograd backward:

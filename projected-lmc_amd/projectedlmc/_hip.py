@@ -42,6 +42,7 @@ _TYPED = {
     "plmc_lmc_kinv_grad": [_I, _P, _L, _L, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "plmc_kernel_vjp": [_I, _P, _I, _P, _I, _I, _P, _P, _P, _L, _L, _P, _P, _P, _I, _P],
     "plmc_qr_small": [_P, _I, _I, _L, _P, _L, _P, _L, _P],
+    "plmc_comm_allreduce_sum": [_P, _L, _P],
     "plmc_posterior_moments": [_P, _L, _L, _L, _I, _P, _P, _I, _P],
     "plmc_mix_posterior": [_P, _P, _P, _I, _I, _I, _c.c_double, _P, _P, _P],
 }
@@ -65,6 +66,11 @@ _PLAIN = {
     "plmc_prof_collect": ([_P, _P, _P, _P], _I),
     "plmc_prof_mfma_rate": ([_I, _P, _L, _P], _I),
     "plmc_dev_reload_knobs": ([], _I),
+    "plmc_comm_unique_id": ([_P], _I),
+    "plmc_comm_init": ([_P, _I, _I], _I),
+    "plmc_comm_world": ([], _I),
+    "plmc_comm_rank": ([], _I),
+    "plmc_comm_destroy": ([], _I),
 }
 
 

@@ -8,6 +8,9 @@ gradient and the scalar loss share (O(q d + p^2) numbers: latency-bound, so a si
 message instead of per-tensor calls); at prediction one all-reduce of the (2, n*, p) partial
 mean / variance sums (projected_lmc.py:1144,1152 is where the cross-latent sum happens).
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -24,9 +27,42 @@ def shard_of(rank=None, world=None):
     return (rank, world)
 
 
+_direct = {"tried": False, "on": False}
+
+
+def _direct_rccl():
+    """PLMC_COMM=rccl: the all-reduces go through the library's own RCCL communicator (plmc_comm_*, include/plmc.h) instead of
+    torch.distributed, which is then used once, to carry the 128-byte unique id from rank 0 to the others.  Default: off."""
+    if _direct["tried"]:
+        return _direct["on"]
+    _direct["tried"] = True
+    if os.environ.get("PLMC_COMM", "") != "rccl" or not is_distributed() or not torch.cuda.is_available():
+        return False
+    from . import _hip
+    L = _hip.lib().cdll
+    dev = torch.device("cuda", torch.cuda.current_device())
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if dist.get_rank() == 0:
+        buf = (ctypes.c_char * 128)()
+        if L.plmc_comm_unique_id(buf) != 0:
+            raise RuntimeError("plmc_comm_unique_id failed: %s" % L.plmc_last_error().decode())
+        uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    uid = uid.to(dev) if dist.get_backend() == "nccl" else uid
+    dist.broadcast(uid, src=0)
+    raw = bytes(uid.cpu().numpy().tobytes())
+    if L.plmc_comm_init(ctypes.c_char_p(raw), dist.get_rank(), dist.get_world_size()) != 0:
+        raise RuntimeError("plmc_comm_init failed: %s" % L.plmc_last_error().decode())
+    _direct["on"] = True
+    return True
+
+
 def all_reduce_sum(t):
     if is_distributed():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if t.is_cuda and t.dtype in (torch.float32, torch.float64) and t.is_contiguous() and _direct_rccl():
+            from . import _hip
+            _hip.lib().call("plmc_comm_allreduce_sum", t.dtype, _hip.ptr(t), t.numel(), _hip.stream_ptr(t.device))
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
@@ -42,8 +78,7 @@ def sync_loss_and_grads(loss, params):
     for p in params:
         g = p.grad if p.grad is not None else torch.zeros_like(p)
         flat.append(g.reshape(-1).to(bdt))
-    buf = torch.cat(flat)
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    buf = all_reduce_sum(torch.cat(flat))
     off = 1
     for p in params:
         k = p.numel()
