@@ -276,7 +276,7 @@ def test_sweeps_from_three_caller_streams_overlap_safely(eng):
         ref.append((ws.A.view(it).clone(), ws.logdet.clone()))
         ws.A.zero_()
     streams = [torch.cuda.Stream(DEV) for _ in probs]
-    for rep in range(3):
+    for rep in range(8):
         torch.cuda.synchronize()
         for (ell, noise, y, ws), s in zip(probs, streams):       # all three in flight together
             with torch.cuda.stream(s):
