@@ -96,6 +96,22 @@ def committed_traffic(kname):
     return None, None
 
 
+def committed_counters(kname):
+    """MfmaUtil (%) and L2 hit rate of `kname` from the newest profiles/rNN_pmc_mfma_l2.json measured on THIS build
+    (tools/collect_pmc_extra.sh), else {}."""
+    import glob
+    key = build_key()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma_l2.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except Exception:
+            continue
+        k = pmc.get("kernels", {}).get(kname)
+        if pmc.get("build_key") == key and k:
+            return {"mfma_util_pct": k.get("MfmaUtil"), "l2_hit_rate": k.get("l2_hit_rate"), "counters_source": os.path.relpath(path, ROOT)}
+    return {}
+
+
 def live_traffic(kname, latents):
     """Two rocprofv3 --pmc child runs of this script (FETCH_SIZE, WRITE_SIZE: separate passes, --kernel-trace only), aggregated
     as tools/pmc_aggregate.py does (hbm bytes = 2 * FETCH + WRITE on gfx950, MI355X_MICROARCH.md).  Returns bytes per launch or None."""
@@ -424,6 +440,7 @@ def main():
                 if tr is None and args.pmc:
                     tr, src = live_traffic(kname, q), "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs"
                 res["roofline"]["traffic"] = tr
+                res["roofline"].update(committed_counters(kname))       # isolated MfmaUtil / L2 hit rate of the same kernel, if profiled on this build
                 res["roofline"]["traffic_note"] = (
                     "bytes/launch, 2*FETCH_SIZE + WRITE_SIZE (%s, build %s); algorithmic tile traffic/launch = %.3g"
                     % (src, build_key(), s["bytes"] / s["launches"]) if tr is not None else

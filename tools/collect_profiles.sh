@@ -12,6 +12,9 @@ python3 $OUT/../tools/pmc_aggregate.py $(find $OUT/pmc_f -name "*counter_collect
 rm -rf $OUT/pmc_f $OUT/pmc_w
 # (the PMC aggregate is keyed on the build: copy it to profiles/ BEFORE the bench line is taken, so that the line quotes it)
 cp $OUT/${R}_pmc_traffic.json $OUT/../profiles/${R}_pmc_traffic.json 2>/dev/null
+# (the same for the MFMA-utilisation / L2-hit-rate passes)
+(cd $OUT/.. && bash tools/collect_pmc_extra.sh $R > /dev/null 2>&1 && cp gpurun_out/${R}_pmc_mfma_l2.json profiles/${R}_pmc_mfma_l2.json)
+cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python3 $OUT/../bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-prof --no-options > /dev/null 2>&1
 cp $(find $OUT/prof_stats -name "*kernel_stats.csv" | head -1) $OUT/${R}_bench_kernel_stats.csv || exit 1
 rm -rf $OUT/prof_stats

@@ -26,4 +26,16 @@ for k, cs in acc.items():
     if "TCC_HIT_sum" in o and "TCC_MISS_sum" in o and o["TCC_HIT_sum"] + o["TCC_MISS_sum"] > 0:
         o["l2_hit_rate"] = o["TCC_HIT_sum"] / (o["TCC_HIT_sum"] + o["TCC_MISS_sum"])
     out[k] = o
-print(json.dumps(out, indent=1))
+import hashlib, os
+def build_key():                                    # as bench.py / tools/pmc_aggregate.py: hash of the library sources
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "projected-lmc_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)) + [os.path.join("..", "..", "include", "plmc.h")]:
+        path = os.path.join(csrc, f)
+        if os.path.isfile(path) and f.endswith((".hip", ".hpp", ".h")):
+            h.update(f.encode() + b"\0" + open(path, "rb").read())
+    return h.hexdigest()[:16]
+print(json.dumps({"build_key": build_key(), "source": "rocprofv3 --kernel-trace --pmc <counters> (one pass per counter group) -- python3 bench.py --steps 2 --warmup 1 "
+                  "--no-cpu-baseline --no-prof --no-options; counter runs serialise the kernels (isolated figures); means over the dispatches",
+                  "kernels": out}, indent=1))
