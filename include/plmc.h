@@ -59,6 +59,9 @@ const char *plmc_last_error(void);            /* text of the last error on the c
  * ABI note: versions 1-3 sized Vd smaller -- a caller built against them must re-query (check plmc_version() == 4). */
 int64_t     plmc_vd_blocks_for(int64_t n_pad, int64_t lda, int elem_bytes);
 int64_t     plmc_vd_blocks(int64_t n_pad, int64_t lda);
+/* ... for a plmc_potrf_ex_f32 call with with_inverse | 4 (the sweep KEEPS the 16-bit planes of every group's solved rows
+ * instead of rolling over two buffers: plmc_potrs_aug_kept_f32 needs them); 4-byte elements only. */
+int64_t     plmc_vd_blocks_keep(int64_t n_pad, int64_t lda);
 /* Bytes of the `partials` scratch plmc_kinv_grad_* needs for (n_pad, q): per-tile partial sums, and for 4-byte elements the
  * bf16 planes of W (6 q n_pad^2 bytes).  plmc_grad_scratch_bytes = the 4-byte size. */
 int64_t     plmc_grad_scratch_bytes_for(int64_t n_pad, int q, int elem_bytes);
@@ -147,6 +150,15 @@ int plmc_potrf_ex_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t s
  */
 int plmc_potrs_aug_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int64_t strideA, float *Vd, int q, void *stream);
 int plmc_potrs_aug_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int64_t strideA, double *Vd, int q, void *stream);
+/* The same against a factorisation that kept its planes -- plmc_potrf_ex_f32(..., with_inverse | 4, ...) into a Vd of
+ * plmc_vd_blocks_keep(n_pad, lda) blocks per latent: the group panels and the depth-1024 updates of the substitution then run on
+ * the split engine too (A operand = the kept planes of the factor's rows; 2-3 x the fp32 MFMA rate of plmc_potrs_aug_f32).
+ * eig_lo: NULL or not as in the factorising call (it selects the scheme; the values are not used).  fp64 and PLMC_SPLIT=0:
+ * exactly plmc_potrs_aug_*. */
+int plmc_potrs_aug_kept_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int64_t strideA, float *Vd, int q,
+                            const float *eig_lo, void *stream);
+int plmc_potrs_aug_kept_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int64_t strideA, double *Vd, int q,
+                            const double *eig_lo, void *stream);
 
 /*
  * Gather augmented column c of every latent into a contiguous vector z (q x n_pad) and return

@@ -717,8 +717,13 @@ __global__ __launch_bounds__(WTMV_NT) void k_w_diag(const T *__restrict__ W, int
 // everywhere).  eig_lo: q lower bounds of the smallest eigenvalue (device), needed by SplitH2 only.
 template <typename T, class S>
 int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *Vd, double *logdet, int *info,
-               int with_inverse, int q, const float *eig_lo, void *stream) {
+               int with_inverse_arg, int q, const float *eig_lo, void *stream) {
   constexpr bool bf3 = !std::is_void<S>::value;
+  // with_inverse & 4 (split engine, with the inverse factor): KEEP the planes of the solved rows of every group instead of
+  // rolling over two buffers -- Vd then has plmc_vd_blocks_keep blocks per latent -- so that plmc_potrs_aug_kept_* can later run
+  // its updates on the split engine too (the eval-mode factorisation cache)
+  const bool keep = bf3 && (with_inverse_arg & 4) != 0 && (with_inverse_arg & 3) != 0;
+  const int with_inverse = with_inverse_arg & 3;
   using SS = typename std::conditional<bf3, S, SplitB3>::type;       // a valid scheme type for the (dead) template arguments when bf3 is off
   constexpr bool aug_fp32 = false;                                     // (the augmented columns have bounds too: k_split_scales)
   PLMC_REQUIRE(A && Vd && logdet && info, "null pointer");
@@ -730,7 +735,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const hipStream_t st = (hipStream_t)stream;
   const int m = (int)(n_pad / NB);
   const int Taug = (int)(naug_pad / NB);
-  const int64_t strideV = plmc_vd_blocks_for(n_pad, lda, (int)sizeof(T)) * (int64_t)NB * NB; // per latent: m diagonal inverses + group scratch
+  const int64_t strideV = (keep ? plmc_vd_blocks_keep(n_pad, lda) : plmc_vd_blocks_for(n_pad, lda, (int)sizeof(T))) * (int64_t)NB * NB; // per latent
   const int64_t wcol0 = n_pad + naug_pad;
   const double nb = (double)NB, nb3 = nb * nb * nb, esz = sizeof(T);
   // group scratch of latent 0 (batch stride strideV): the inverse triangle Wg and two transposed copies (ping-pong:
@@ -760,7 +765,10 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const int64_t pl_lat = strideV * (int64_t)(sizeof(T) / 2);            // latent stride in 16-bit elements
   const int64_t sc_lat = strideV * (int64_t)sizeof(T) / 4;              // ... in floats
   const int grp_rows = (knobs().grp > 0 && knobs().grp < GMAX) ? knobs().grp : GMAX;   // block rows per group (as below)
+  // (keep: one buffer per group, behind the planes of W)
+  unsigned short *const Uk0 = keep ? reinterpret_cast<unsigned short *>(reinterpret_cast<float *>(Wk) + vd_wk_blocks(n_pad, lda, 4) * (int64_t)NB * NB) : nullptr;
   auto planes = [&](int g0) -> unsigned short * {                       // buffer of the group that starts at block row g0
+    if (keep) return Uk0 + (int64_t)(g0 / grp_rows) * pl_buf;
     return bf3 ? Pl0 + (int64_t)((g0 / grp_rows) & 1) * pl_buf : nullptr;
   };
   const bool kacc_on = with_inverse == 2;
@@ -1171,6 +1179,78 @@ int potrs_aug_at(T *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int6
   return launch_status("plmc_potrs_aug");
 }
 
+// The scales of the augmented operand families (SC_SA, SC_RA) for NEW augmented columns of a KEPT factorisation: k_scale_scan has
+// just left the largest |augmented entry| of each row slice behind the scales (its diagonal figures are those of U now and are
+// ignored); D and lambda of the factorised matrix are still in the scale block (k_split_scales).  grid (q), 64 threads.
+template <class S>
+__global__ __launch_bounds__(64) void k_aug_scales(int64_t n_pad, float *__restrict__ sc, int64_t sc_stride) {
+  if constexpr (S::NPL == 3) return;                                  // SplitB3: all scales are 1
+  if (threadIdx.x != 0) return;
+  float *o = sc + (int64_t)blockIdx.x * sc_stride;
+  float amax = 0.0f;
+  for (int p = 0; p < SCAN_PARTS; ++p) amax = fmaxf(amax, o[SC_N + 3 * p + 2]);
+  const float D = o[6], lam = o[7];
+  const float Rn = sqrtf((float)n_pad) * amax + 1e-30f;
+  o[SC_SA] = b3_scale_for(Rn / sqrtf(lam));
+  o[SC_RA] = b3_scale_for(Rn * (1.0f + sqrtf(D / lam)));
+}
+
+// The same forward substitution on the split engine, against a factorisation that KEPT its planes (plmc_potrf_ex_f32 with
+// with_inverse | 4; Vd sized by plmc_vd_blocks_keep): per group the planes of Vgg from the W columns (k_vtrans), the group panel
+// of the augmented columns (k_gpanel_bf3: in place + planes), one depth-(128 G) macro-tile update of the rows below whose A
+// operand is the kept planes of the group's U rows; its epilogue writes the raw planes of the next group's rows.  One stream.
+template <class S>
+int potrs_aug_kept(float *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int64_t strideA, float *Vd, int q, void *stream) {
+  PLMC_REQUIRE(A && Vd, "null pointer");
+  PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0 && lda % NB == 0 && wcol0 % NB == 0, "n_pad / lda / wcol0 must be multiples of NB");
+  const int64_t naug_pad = plmc_pad(naug);
+  PLMC_REQUIRE(naug > 0 && q > 0 && n_pad + naug_pad <= wcol0 && wcol0 + n_pad <= lda, "augmented columns must fit between the square part and the W columns");
+  PLMC_REQUIRE(aligned16(A) && aligned16(Vd), "unaligned buffer");
+  const hipStream_t st = (hipStream_t)stream;
+  const int m = (int)(n_pad / NB), Tu = (int)(naug_pad / NB);
+  const int64_t strideV = plmc_vd_blocks_keep(n_pad, lda) * (int64_t)NB * NB;
+  const double nb = (double)NB, nb3 = nb * nb * nb;
+  // the scratch layout of potrf_impl (fp32)
+  float *const Wg = Vd + (int64_t)m * NB * NB;
+  float *const Vg2[2] = {Wg + (int64_t)GMAX * NB * LDG, Wg + 2 * (int64_t)GMAX * NB * LDG};
+  float *const Pbulk = Wg + 4 * (int64_t)GMAX * NB * LDG;
+  const int64_t pl_buf = b3_elems<SplitB3>((int64_t)GMAX * NB, lda), vgp_elems = b3_elems<SplitB3>((int64_t)GMAX * NB, (int64_t)GMAX * NB);
+  unsigned short *const Pl0 = reinterpret_cast<unsigned short *>(Pbulk + (int64_t)GMAX * NB * lda);
+  unsigned short *const Praw = Pl0 + 2 * pl_buf;
+  unsigned short *const VgP2[2] = {Praw + pl_buf, Praw + pl_buf + vgp_elems};
+  float *const scl = reinterpret_cast<float *>(VgP2[1] + vgp_elems);
+  unsigned short *const Wk = reinterpret_cast<unsigned short *>(scl + (int64_t)NB * NB);
+  unsigned short *const Uk0 = reinterpret_cast<unsigned short *>(reinterpret_cast<float *>(Wk) + vd_wk_blocks(n_pad, lda, 4) * (int64_t)NB * NB);
+  const int64_t pl_lat = strideV * 2, sc_lat = strideV;
+  float *const WA = A + wcol0;
+  const ColMap<float> cm{0, 0, Tu, 0, 0, n_pad, (float *)nullptr, lda, strideA};
+  hipLaunchKernelGGL(k_scale_scan, dim3(SCAN_PARTS, q), dim3(NTHREADS), 0, st, (const float *)A, n_pad, lda, strideA, (int)naug_pad, scl, sc_lat);
+  hipLaunchKernelGGL((k_aug_scales<S>), dim3(q), dim3(64), 0, st, n_pad, scl, sc_lat);
+  const int G0 = GMAX < m ? GMAX : m;
+  hipLaunchKernelGGL((k_raw_planes<S>), dim3(Tu, G0, q), dim3(NTHREADS), 0, st, (const float *)A, lda, strideA, 0, cm, Praw, pl_lat, wcol0, (const float *)scl,
+                     sc_lat);
+  for (int g0 = 0, gi = 0; g0 < m; g0 += GMAX, ++gi) {
+    const int g1 = g0 + GMAX < m ? g0 + GMAX : m, g2 = g1 + GMAX < m ? g1 + GMAX : m, G = g1 - g0, nm = (G + 1) / 2;
+    unsigned short *const Pg = Uk0 + (int64_t)gi * pl_buf;
+    hipLaunchKernelGGL((k_vtrans<float, S>), dim3(GMAX * GMAX, q), dim3(NTHREADS), 0, st, (const float *)(WA + (int64_t)g0 * NB * lda + (int64_t)g0 * NB), lda,
+                       strideA, strideV, Vg2[gi & 1], G, (float *)nullptr, lda, strideA, VgP2[gi & 1], pl_lat, (const float *)scl, sc_lat);
+    {
+      const double prods = G * (G + 1) / 2.0;
+      ProfScope ps(PK_GPANEL, st, q * (double)Tu * prods * 2.0 * nb3, q * (double)Tu * (prods + G) * nb * nb * 4.0);
+      hipLaunchKernelGGL((k_gpanel_bf3<S>), dim3(Tu, (nm + 1) / 2, q), dim3(B3_NT), 0, st, A, lda, strideA, g0, G, cm, (const unsigned short *)VgP2[gi & 1], pl_lat,
+                         (const unsigned short *)Praw, pl_lat, Pg, pl_lat, wcol0, (const float *)scl, sc_lat, 1, Wk, pl_lat);
+    }
+    if (g1 < m) {
+      const int nrows = m - g1;
+      const double tiles = (double)Tu * nrows;
+      ProfScope ps(PK_TRAIL, st, q * tiles * 2.0 * nb * nb * (G * nb), q * 2.0 * tiles * nb * nb * 4.0);
+      hipLaunchKernelGGL((k_update_bf3<S, 0>), dim3(Tu, (nrows + 1) / 2, q), dim3(B3_NT), 0, st, A, lda, strideA, g1, nrows, g0, g1 - 1, cm, 0, 0,
+                         (const unsigned short *)Pg, pl_lat, wcol0, Praw, pl_lat, g2, (const float *)scl, sc_lat, (const unsigned short *)Wk, pl_lat);
+    }
+  }
+  return launch_status("plmc_potrs_aug_kept");
+}
+
 template <typename T>
 int extract_col_impl(const T *A, int64_t n_pad, int64_t lda, int64_t strideA, int c, T *z, double *quad, int q,
                      void *stream) {
@@ -1219,6 +1299,12 @@ int64_t plmc_vd_blocks_for(int64_t n_pad, int64_t lda, int elem_bytes) {
   return 2 * (n_pad / plmc::NB) + plmc::VD_FIXED_BLOCKS + plmc::GMAX * ldb + planes + plmc::vd_wk_blocks(n_pad, lda, elem_bytes);
 }
 int64_t plmc_vd_blocks(int64_t n_pad, int64_t lda) { return plmc_vd_blocks_for(n_pad, lda, 4); }
+// ... when the sweep keeps the planes of every group's solved rows (with_inverse | 4, fp32): one 128 GMAX-row plane buffer per
+// group instead of the two rolling ones
+int64_t plmc_vd_blocks_keep(int64_t n_pad, int64_t lda) {
+  const int64_t ldb = (lda + plmc::NB - 1) / plmc::NB, m = n_pad / plmc::NB;
+  return plmc_vd_blocks_for(n_pad, lda, 4) + ((m + plmc::GMAX - 1) / plmc::GMAX) * (3 * plmc::GMAX * ldb / 2);
+}
 // PLMC_SPLIT picks the arithmetic of the bulk fp32 products: 0 = fp32 MFMA everywhere, 3 = SplitB3, 2 (default) = SplitH2
 // where the caller supplies eigenvalue bounds (plmc_potrf_ex_f32), SplitB3 otherwise.
 static int potrf_f32_any(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet, int *info,
@@ -1250,6 +1336,20 @@ int plmc_potrs_aug_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t w
   return plmc::potrs_aug_at<float>(A, n_pad, lda, naug, wcol0, strideA, Vd, q, stream);
 }
 int plmc_potrs_aug_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int64_t strideA, double *Vd, int q, void *stream) {
+  return plmc::potrs_aug_at<double>(A, n_pad, lda, naug, wcol0, strideA, Vd, q, stream);
+}
+// ... against a factorisation that kept its planes (plmc_potrf_ex_f32 with with_inverse | 4, Vd of plmc_vd_blocks_keep blocks per
+// latent): the updates run on the split engine of that factorisation (same PLMC_SPLIT, eig_lo given or not as there)
+int plmc_potrs_aug_kept_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int64_t strideA, float *Vd, int q, const float *eig_lo,
+                            void *stream) {
+  const int split = plmc::knobs().split;
+  if (split == 0) return plmc::potrs_aug_at<float>(A, n_pad, lda, naug, wcol0, strideA, Vd, q, stream);   // (that sweep ignored the flag)
+  if (split == 2 && eig_lo) return plmc::potrs_aug_kept<plmc::SplitH2>(A, n_pad, lda, naug, wcol0, strideA, Vd, q, stream);
+  return plmc::potrs_aug_kept<plmc::SplitB3>(A, n_pad, lda, naug, wcol0, strideA, Vd, q, stream);
+}
+int plmc_potrs_aug_kept_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t wcol0, int64_t strideA, double *Vd, int q, const double *eig_lo,
+                            void *stream) {
+  (void)eig_lo;
   return plmc::potrs_aug_at<double>(A, n_pad, lda, naug, wcol0, strideA, Vd, q, stream);
 }
 int plmc_extract_col_f32(const float *A, int64_t n_pad, int64_t lda, int64_t strideA, int c, float *z, double *quad,

@@ -22,10 +22,13 @@ class Workspace:
     """Caller-owned device buffers for q latent GPs on n points with naug augmented columns.
     Layout documented in include/plmc.h."""
 
-    def __init__(self, n, q, naug, dtype, device, with_inverse=True):
+    def __init__(self, n, q, naug, dtype, device, with_inverse=True, keep_planes=False):
         L = _hip.lib()
         self.n, self.q, self.naug, self.dtype, self.device = n, q, naug, dtype, device
         self.with_inverse = bool(with_inverse)
+        # keep_planes (fp32, with the inverse factor): the sweep keeps the 16-bit planes of every group's solved rows, so that new
+        # augmented columns can be forward-substituted on the split engine (plmc_potrs_aug_kept): the eval-mode cache
+        self.keep_planes = bool(keep_planes) and self.with_inverse and dtype == torch.float32
         self.NB = L.cdll.plmc_block()
         self.n_pad = int(L.cdll.plmc_pad(n))
         self.naug_pad = int(L.cdll.plmc_pad(naug)) if naug > 0 else 0
@@ -36,7 +39,8 @@ class Workspace:
         self.strideA = self.n_pad * self.lda
         esz = torch.empty((), dtype=dtype).element_size()
         # scratch sizes depend on (n_pad, lda, element size) only -- never on a dev knob (include/plmc.h, version 3)
-        self.Vd = torch.empty(q, int(L.cdll.plmc_vd_blocks_for(self.n_pad, self.lda, esz)), self.NB, self.NB, dtype=dtype, device=device)
+        vd_blocks = L.cdll.plmc_vd_blocks_keep(self.n_pad, self.lda) if self.keep_planes else L.cdll.plmc_vd_blocks_for(self.n_pad, self.lda, esz)
+        self.Vd = torch.empty(q, int(vd_blocks), self.NB, self.NB, dtype=dtype, device=device)
         self.m = self.n_pad // self.NB
         self.A = torch.empty(q, self.n_pad, self.lda, dtype=dtype, device=device)
         self.logdet = torch.empty(q, dtype=torch.float64, device=device)
@@ -138,7 +142,8 @@ def factorize(kind, X, ell, oscale, noise, rhs, ws, Xs=None, kacc=False):
     # eig_lo = the noise variances: lambda_min(K + s2 I) >= s2 -- the bound the two-plane fp16 split of the bulk fp32 products
     # scales its operands with (include/plmc.h, plmc_potrf_ex_*); ignored by the fp64 entry point
     L.call("plmc_potrf_ex", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.naug, ws.strideA, _hip.ptr(ws.Vd),
-           _hip.ptr(ws.logdet), _hip.ptr(ws.info), (2 if kacc else 1) if ws.with_inverse else 0, q, _hip.ptr(noise), st)
+           _hip.ptr(ws.logdet), _hip.ptr(ws.info), ((2 if kacc else 1) | (4 if ws.keep_planes else 0)) if ws.with_inverse else 0, q,
+           _hip.ptr(noise), st)
 
 
 def sweep_accumulates_kinv():
@@ -473,11 +478,15 @@ def exact_posterior(kind, X, ell, oscale, noise, y, Xs, full_cov=False, cache=No
             L.call("plmc_write_rhs", dt, _hip.ptr(yc), 1, n, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, ws.naug_pad, q, st)
             L.call("plmc_assemble_cross", dt, k, _hip.ptr(Xc), n, _hip.ptr(Xsc), ns, Xc.shape[1], _hip.ptr(ellc), _hip.ptr(osc),
                    _hip.ptr(ws.A), ws.lda, ws.strideA, ws.n_pad + 1, ws.n_pad, q, st)
-            L.call("plmc_potrs_aug", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, 1 + ns, ws.wcol0, ws.strideA, _hip.ptr(ws.Vd), q, st)
+            if ws.keep_planes:
+                L.call("plmc_potrs_aug_kept", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, 1 + ns, ws.wcol0, ws.strideA, _hip.ptr(ws.Vd), q,
+                       _hip.ptr(nzc), st)
+            else:
+                L.call("plmc_potrs_aug", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, 1 + ns, ws.wcol0, ws.strideA, _hip.ptr(ws.Vd), q, st)
         else:
             cache.misses += 1
             cache.drop()
-            ws = Workspace(n, q, 1 + ns, dt, dev, with_inverse=True)
+            ws = Workspace(n, q, 1 + ns, dt, dev, with_inverse=True, keep_planes=True)
             factorize_checked(kind, Xc, ellc, osc, nzc, yc, ws, Xs=Xsc)
             cache.key, cache.ws = key, ws
     # mean = V^T z and |v|^2 per test point: one pass over the augmented columns (plmc_posterior_moments)

@@ -29,6 +29,7 @@ _TYPED = {
     "plmc_potrf": [_P, _L, _L, _I, _L, _P, _P, _P, _I, _I, _P],
     "plmc_potrf_ex": [_P, _L, _L, _I, _L, _P, _P, _P, _I, _I, _P, _P],
     "plmc_potrs_aug": [_P, _L, _L, _I, _L, _L, _P, _I, _P],
+    "plmc_potrs_aug_kept": [_P, _L, _L, _I, _L, _L, _P, _I, _P, _P],
     "plmc_extract_col": [_P, _L, _L, _L, _I, _P, _P, _I, _P],
     "plmc_wt_matvec": [_P, _L, _L, _L, _P, _P, _I, _P],
     "plmc_w_diag": [_P, _L, _L, _L, _P, _I, _P],
@@ -52,6 +53,7 @@ _PLAIN = {
     "plmc_pad": ([_L], _L),
     "plmc_vd_blocks": ([_L, _L], _L),
     "plmc_vd_blocks_for": ([_L, _L, _I], _L),
+    "plmc_vd_blocks_keep": ([_L, _L], _L),
     "plmc_max_dim": ([], _I),
     "plmc_qr_max": ([], _I),
     "plmc_last_error": ([], _c.c_char_p),
