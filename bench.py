@@ -207,7 +207,7 @@ def main():
     ap.add_argument("--variant", default="PLMC_fast", choices=["PLMC_fast", "PLMC"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--no-options", action="store_true", help="skip the run with PLMC_BF16X3=0 (fp32 MFMA everywhere) that is reported beside the headline")
+    ap.add_argument("--no-options", action="store_true", help="skip the runs with PLMC_SPLIT=0 (fp32 MFMA everywhere) and PLMC_SPLIT=3 (three bf16 planes) that are reported beside the headline")
     ap.add_argument("--pmc", action="store_true", help="measure roofline.traffic live (two rocprofv3 --pmc child runs) "
                                                       "when no profile of this build is committed")
     args = ap.parse_args()
@@ -408,7 +408,7 @@ def main():
             s = mf[dom]
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
             # the three bracketed classes are exactly the launches the split engine carries: their peak is the dense bf16 peak
-            # divided by the six plane products one fp32 product costs (fp32-equivalent TFLOP/s); with PLMC_BF16X3=0 the fp32 peak
+            # divided by the six plane products one fp32 product costs (fp32-equivalent TFLOP/s); with PLMC_SPLIT=0 the fp32 peak
             peak = MFMA_PEAK_TFLOPS["bf16"] / SPLIT_PRODUCTS[split] if split else MFMA_PEAK_TFLOPS["f32"]
             try:                                                  # bare instruction stream on this device, now (f16 runs at the bf16 rate)
                 peak_meas = (_hip.mfma_rate("bf16", dev) / SPLIT_PRODUCTS[split]) if split else _hip.mfma_rate(torch.float32, dev)

@@ -223,9 +223,9 @@ __global__ __launch_bounds__(64) void k_split_scales(int64_t n_pad, const float 
   }
 }
 
-// fp32, PLMC_BF16X3 (the fp32 default): the bulk trailing updates (tail, head rows) with their depth-(128 G) products on the
-// bf16 matrix cores (bf3_engine.hpp).  A workgroup of 512 threads takes the macro tile (block rows ib, ib + 1) x (column tile
-// bx).  The operands are the panel rows of the current group, which k_gpanel_copy / k_wtri_planes also write as k8-ordered
+// fp32, split engine (PLMC_SPLIT != 0, the fp32 default): the bulk trailing updates (tail, head, look-ahead) with their depth-(128 G)
+// products on the 16-bit matrix cores (bf3_engine.hpp).  A workgroup of 512 threads takes the macro tile (block rows ib, ib + 1) x (column tile
+// bx).  The operands are the panel rows of the current group, which k_gpanel_bf3 / k_wtri_planes also write as k8-ordered
 // bf16 planes into a rolling two-group buffer `Pl` (per buffer b3_elems(128 GMAX, lda) elements, same column coordinates as
 // the factor buffer); tile decoding, skip and depth rules and the write-back are those of k_update, per half.
 // Block rows ib < raw_end are the NEXT group's rows and this is their last update: their final values also go, as planes,
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(NTHREADS) void k_wtri_planes(const float *__restric
                            sc[(int64_t)lat * sc_stride + SC_SW], nullptr, 0, threadIdx.x);
 }
 
-// PLMC_BF16X3 (fp32): rows of the factor buffer as planes of `Praw` -- the raw (not yet solved) rows of the FIRST group, which
+// Split engine (fp32): rows of the factor buffer as planes of `Praw` -- the raw (not yet solved) rows of the FIRST group, which
 // no update kernel has written (every later group's raw rows come out of k_update_bf3).  grid (tiles of the column map, G, q).
 template <class S>
 __global__ __launch_bounds__(NTHREADS) void k_raw_planes(const float *__restrict__ A, int64_t lda, int64_t strideA, int g0, ColMap<float> cm,
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(NTHREADS) void k_raw_planes(const float *__restrict
                            threadIdx.x);
 }
 
-// PLMC_BF16X3 (fp32): the group panel on the bf16 matrix cores.  P[i] = sum_{k <= i} Vgg[k][i]^T A[k] for the block rows
+// Split engine (fp32): the group panel on the 16-bit matrix cores.  P[i] = sum_{k <= i} Vgg[k][i]^T A[k] for the block rows
 // i of the group and one 128-column strip t of the column map, from the planes of Vgg (VgP, k_vtrans) and of the raw
 // rows (Praw: k_update_bf3 of the previous group / k_raw_planes).  The operands are read from plane buffers only, so the
 // result goes IN PLACE into the factor buffer -- no panel buffer, no copy kernel -- and, while the tile is in LDS, as planes
@@ -812,7 +812,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // cls: profiler class of the launch -- PK_TRAIL (the big trailing update), PK_TRAIL_HEAD (look-ahead updates of the next
   // group's rows: `crit` = the triangle on the chain stream, else the other columns on the second helper stream),
   // PK_TRAIL_ROW (rank-128 update inside a group's triangle)
-  // raw_end (PLMC_BF16X3): block rows below it are the next group's -- this launch is their last update and also writes
+  // raw_end (split engine): block rows below it are the next group's -- this launch is their last update and also writes
   // their planes (Praw) for the next group panel
   auto update = [&](int ib0, int nrows, int r_lo, int r_hi, const ColMap<T> &cm, hipStream_t s, int cls, int skip_ib = 0,
                     int skip_jb = 0, bool crit = false, int raw_end = 0) {
@@ -976,7 +976,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     hipLaunchKernelGGL((k_vtrans<T, S>), dim3(bf3 ? GMAX * GMAX : G * (G + 1) / 2, q), dim3(NTHREADS), 0, s, (const T *)Wg, (int64_t)LDG, strideV,
                        strideV, Vg2[gi & 1], G, wo, lda, strideA, VgP2[gi & 1], pl_lat, (const float *)scl, sc_lat);
   };
-  // PLMC_BF16X3: planes of the group's inverse triangle (read back from the W columns k_vtrans wrote; any stream behind it)
+  // split engine: planes of the group's inverse triangle (read back from the W columns k_vtrans wrote; any stream behind it)
   auto wtri_planes = [&](int gi, hipStream_t s) {
     if constexpr (bf3) {
       if (!WA) return;
@@ -985,7 +985,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
                          n_pad);
     }
   };
-  // PLMC_BF16X3: planes of the first group's raw rows (columns of the bulk panel: everything right of the second group + aug)
+  // split engine: planes of the first group's raw rows (columns of the bulk panel: everything right of the second group + aug)
   auto raw_planes0 = [&](hipStream_t s, int u0) {
     if constexpr (bf3) {
       const int g1 = G0(1);
@@ -1030,8 +1030,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   const bool la = C && H && e_entry && e_v && e_gh && e_p && e_hd && e_tail && e_doneC && e_doneH && e_prev && ng > 2;
   if (!la) {
     // one stream: chain -> transpose -> group panel over every column -> trailing update of every row below
-    // PLMC_BF16X3: which engine a tile goes through must not depend on the schedule -- as under the look-ahead, the panel
-    // columns of the next group and its triangle update (U1) take the fp32 MFMAs, everything else the bf16 engine
+    // split engine: which engine a tile goes through must not depend on the schedule -- the same launches as under the look-ahead
+    // (head panel, rest panel, tail, U1), one after the other
     raw_planes0(st, G0(1));
     for (int gi = 0; gi < ng; ++gi) {
       const int g0 = G0(gi), g1 = G0(gi + 1);
@@ -1287,7 +1287,7 @@ int w_diag_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, T *kinv
 
 extern "C" {
 // Vd blocks per latent: m diagonal inverses + the fixed group scratch + the bulk panel buffer (GMAX block rows of lda) + m
-// diagonal K^-1 tiles; for 4-byte elements also the bf16 plane buffers of the bf16 engine -- whether or not PLMC_BF16X3 is
+// diagonal K^-1 tiles; for 4-byte elements also the plane buffers of the split engine -- whether or not PLMC_SPLIT is
 // on, so that a workspace never depends on a knob.
 int64_t plmc_vd_blocks_for(int64_t n_pad, int64_t lda, int elem_bytes) {
   const int64_t ldb = (lda + plmc::NB - 1) / plmc::NB;

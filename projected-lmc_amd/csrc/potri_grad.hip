@@ -176,9 +176,10 @@ __global__ __launch_bounds__(NTHREADS, (KG_MIN_WAVES<T, DCAP>)) void k_kinv_grad
 #undef PLMC_KINV_KEEP
 }
 
-// The same on the bf16 matrix cores (fp32 only; bf3_engine.hpp): a workgroup of 512 threads takes the macro tile
-// (ib, ib + 1) x jb of K^-1 = W^T W from the k8-ordered planes of W (`Wp`, written by k_split_w; per latent
-// b3_elems(n_pad, n_pad) 16-bit elements), then each half of 256 threads runs the gradient epilogue on its own tile.
+// The same on the 16-bit matrix cores (fp32 only; bf3_engine.hpp): a workgroup of 512 threads takes the macro tile
+// (ib, ib + 1) x jb of K^-1 = W^T W from the k8-ordered planes of W (`Wp`, n_pad columns per plane row, `wp_lat_stride` elements
+// per latent: the planes the sweep left in its Vd scratch, or the ones k_split_w writes behind the partials), then each half of
+// 256 threads runs the gradient epilogue on its own tile.
 // `wscale`: per latent the power-of-two scale the planes of W were written with (SplitH2; SplitB3: ones).
 template <class S, int DCAP, bool SPLINE = false>
 __global__ __launch_bounds__(B3_NT, 2) void k_kinv_grad_bf3(int kind, int64_t n_pad, const float *__restrict__ alpha, const float *__restrict__ X, int n,
@@ -503,7 +504,7 @@ int plmc_grad_tiles_f64(int kind, const double *A, int64_t n_pad, int64_t lda, i
                         void *partials, int q, void *stream) {
   return plmc::grad_tiles_impl<double>(kind, A, n_pad, lda, strideA, Vd, alpha, X, n, d, ell, oscale, grad, kinv_diag, partials, q, stream);
 }
-// per-tile partial sums + (4-byte elements) the bf16 planes of W for the bf16 engine; independent of the knobs
+// per-tile partial sums + (4-byte elements) the planes of W for the split engine (the entry points without Vd); independent of the knobs
 int64_t plmc_grad_scratch_bytes_for(int64_t n_pad, int q, int elem_bytes) {
   int64_t m = n_pad / plmc::NB;
   const int64_t planes = elem_bytes == 4 ? (int64_t)q * plmc::b3_elems<plmc::SplitB3>(n_pad, n_pad) * 2 + 4096 : 0;   // + the q scales
