@@ -48,10 +48,40 @@ def test_second_call_hits_the_cache_and_matches_first_call_and_oracle(dtype, tol
         assert (got.mean.cpu().double() - want).abs().max() < tol * max(1.0, float(want.abs().max()))
         assert (gotv.cpu().double() - wantv).abs().max() < tol * max(1.0, float(wantv.abs().max()))
     # first and second call: the same factor, different routes for the augmented columns (inside the sweep -- fp32: on the split
-    # engine -- vs. the forward substitution on the MFMA of the element type): they agree far inside the oracle tolerance
+    # engine -- vs. the forward substitution of the cached call): they agree far inside the oracle tolerance
     agree = 1e-10 if dtype == torch.float64 else 5e-5
     assert (o1.mean - o1b.mean).abs().max() < agree * max(1.0, float(o1.mean.abs().max()))
     assert (o1.variance - o1b.variance).abs().max() < agree * max(1.0, float(o1.variance.abs().max()))
+
+
+def test_cached_substitution_on_the_split_engine_over_three_groups_fp32():
+    """n = 2600: three groups of block rows, so the cached call (plmc_potrs_aug_kept: fp32, planes of the factor kept by the
+    caching sweep) runs all of its pieces -- scales of the new columns, raw planes of the first group, group panels, the depth-1024
+    macro-tile updates of the rows below whose epilogues write the next group's raw planes, a ragged last group -- against the
+    oracle, against the first call, and with a smaller second batch of test points."""
+    from oracle import projected as oproj
+    from _bridge import oracle_params
+    m, X, Y = _model(n=2600, d=4, p=4, q=2, seed=3, dtype=torch.float32, BDN=False)
+    P = oracle_params(m)
+    g = torch.Generator().manual_seed(8)
+    Xs1 = 2 * torch.rand(333, 4, generator=g, dtype=torch.float32) - 1
+    Xs2 = 2 * torch.rand(150, 4, generator=g, dtype=torch.float32) - 1
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        o1 = m(Xs1.to(DEV))
+        c = m._prediction_cache()
+        assert c.ws is not None and c.ws.keep_planes and c.ws.m == 21
+        o1b = m(Xs1.to(DEV))
+        o2 = m(Xs2.to(DEV))
+        assert (c.hits, c.misses) == (2, 1)
+    mean1, cov1 = oproj.task_posterior(P, X.double(), Y.double(), Xs1.double())
+    mean2, cov2 = oproj.task_posterior(P, X.double(), Y.double(), Xs2.double())
+    var1, var2 = torch.diagonal(cov1).reshape(Xs1.shape[0], -1), torch.diagonal(cov2).reshape(Xs2.shape[0], -1)
+    for got, want, wantv in ((o1, mean1, var1), (o1b, mean1, var1), (o2, mean2, var2)):
+        assert (got.mean.cpu().double() - want).abs().max() < 2e-4 * max(1.0, float(want.abs().max()))
+        assert (got.variance.cpu().double() - wantv).abs().max() < 2e-4 * max(1.0, float(wantv.abs().max()))
+    assert (o1.mean - o1b.mean).abs().max() < 5e-5 * max(1.0, float(o1.mean.abs().max()))
+    assert (o1.variance - o1b.variance).abs().max() < 5e-5 * max(1.0, float(o1.variance.abs().max()))
 
 
 def test_cache_is_dropped_when_the_model_changes():
