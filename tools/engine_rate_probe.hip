@@ -66,7 +66,7 @@ __global__ __launch_bounds__(B3_NT, 2) void k_rate(const unsigned short *__restr
 // resident workgroups share BR A strips and BC B strips), blocks dealt round-robin to the XCDs along the rows.
 template <class S, int NSTG, int ORDER, int BR, int BC, int EPI = 2>
 __global__ __launch_bounds__(B3_NT, 2) void k_tail(const unsigned short *__restrict__ P, int64_t pstride, float *C, int64_t cstride, int64_t ld, int K,
-                                                    int mrows, int nU, int nF) {
+                                                    int mrows, int nU, int nF, int tri = 1) {
   __shared__ __align__(16) unsigned char lds[NSTG * b3_stage_bytes<S>()];
   const int tcols = nU + nF;
   int mb, jb;
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(B3_NT, 2) void k_tail(const unsigned short *__restr
   }
   const int lat = blockIdx.z;
   bool v0 = true, v1 = true;
-  if (jb < nU) { v0 = jb >= 2 * mb; v1 = jb >= 2 * mb + 1; }
+  if (tri && jb < nU) { v0 = jb >= 2 * mb; v1 = jb >= 2 * mb + 1; }
   if (!v0 && !v1) return;
   const unsigned short *Pl = P + (int64_t)lat * pstride;
   Acc<float> acc0, acc1;
@@ -132,6 +132,49 @@ int run_tail_one(const char *name, const unsigned short *P, int64_t pstride, flo
     for (int jb = 0; jb < tcols; ++jb) tiles += jb < nU ? (jb >= 2 * mb) + (jb >= 2 * mb + 1) : 2;
   const double us = 1e3 * ms / reps;
   printf("  %-58s %9.1f us per launch  %7.1f TF fp32-equivalent\n", name, us, 2.0 * 128 * 128 * (double)K * tiles * q / (us * 1e-6) / 1e12);
+  return 0;
+}
+
+// What separates the loop's 457 TF on a small, L2-resident working set from ~370 TF on the tail's shape?  The same kernel (no
+// epilogue, shipped order) over shapes between the two: rows x columns, latents, with / without the triangle.
+int run_shapes() {
+  typedef SplitH2 S;
+  const int K = 1024;
+  struct Shape { int mr, nu, nf, q, tri; const char *what; };
+  const Shape shapes[] = {{16, 32, 0, 1, 0, "16 x 32, 1 latent, all tiles (the K-sweep probe's shape)"}, {16, 32, 0, 8, 0, "16 x 32, 8 latents"},
+                          {24, 48, 17, 1, 0, "24 x 65, 1 latent, all tiles"}, {24, 48, 17, 8, 0, "24 x 65, 8 latents, all tiles"},
+                          {24, 48, 17, 8, 1, "24 x 65, 8 latents, triangle (the tail's shape)"}, {8, 48, 17, 8, 0, "8 x 65, 8 latents"},
+                          {24, 16, 0, 8, 0, "24 x 16, 8 latents"}, {24, 130, 0, 2, 0, "24 x 130, 2 latents"}};
+  for (const Shape &sh : shapes) {
+    const int64_t ld = (int64_t)(sh.nu + sh.nf > 2 * sh.mr ? sh.nu + sh.nf : 2 * sh.mr) * NB + 128;
+    const int64_t pstride = b3_elems<S>(K, ld), cstride = (int64_t)sh.mr * 256 * ld;
+    unsigned short *P = nullptr;
+    float *C = nullptr;
+    CK(hipMalloc(&P, (size_t)pstride * sh.q * 2));
+    CK(hipMalloc(&C, (size_t)cstride * sh.q * 4));
+    for (int l = 0; l < sh.q; ++l)
+      hipLaunchKernelGGL((k_fill<S>), dim3((unsigned)((ld + NTHREADS - 1) / NTHREADS), K / 8), dim3(NTHREADS), 0, 0, P + (int64_t)l * pstride, ld, K, 99u + l);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const dim3 grid(sh.nu + sh.nf, sh.mr, sh.q);
+    auto launch = [&]() { hipLaunchKernelGGL((k_tail<S, 2, 0, 1, 1, 0>), grid, dim3(B3_NT), 0, 0, P, pstride, C, cstride, ld, K, sh.mr, sh.nu, sh.nf, sh.tri); };
+    for (int w = 0; w < 3; ++w) launch();
+    float ms = 0.f;
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 8; ++r) launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    double tiles = 0;
+    for (int mb = 0; mb < sh.mr; ++mb)
+      for (int jb = 0; jb < sh.nu + sh.nf; ++jb) tiles += (sh.tri && jb < sh.nu) ? (jb >= 2 * mb) + (jb >= 2 * mb + 1) : 2;
+    const double us = 1e3 * ms / 8;
+    printf("  %-62s planes %4.0f MB  %8.1f us  %6.1f TF\n", sh.what, pstride * 2.0 * sh.q / 1e6, us, 2.0 * 128 * 128 * (double)K * tiles * sh.q / (us * 1e-6) / 1e12);
+    CK(hipFree(P));
+    CK(hipFree(C));
+  }
   return 0;
 }
 
@@ -221,6 +264,7 @@ template <class S> int run(const char *name, int products) {
 }
 
 int main(int argc, char **argv) {
+  if (argc > 1 && argv[1][0] == 's') return run_shapes();
   if (run_tail()) return 1;
   if (argc < 2) return 0;                                    // any argument: also the K sweep of the bare loop
   if (run<SplitH2>("SplitH2 (two fp16 planes)", 3)) return 1;
