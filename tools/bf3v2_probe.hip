@@ -5,6 +5,9 @@
 // accumulator levels, 256 x 128 macro tile per workgroup, k8-ordered planes through LDS-DMA).  Reports time per launch,
 // TFLOP/s on 2 * 128^2 * K per tile, and the error of both against an fp64 host product on sample tiles.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/bf3v2_probe tools/bf3v2_probe.hip
+// HISTORICAL: written against the first form of bf3_engine.hpp (commit 'bf16x3 engine, second form'; its outputs are
+// profiles/r03_bf3v2_probe_*.txt).  The engine's interface has moved on (scheme template parameter, pre-load hook);
+// tools/engine_rate_probe.hip is the probe that builds against the current header.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>

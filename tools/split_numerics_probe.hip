@@ -1,5 +1,5 @@
 // split_numerics_probe.hip -- which split of fp32 operands over the 16-bit matrix cores is as accurate as the fp32 MFMA
-// chain?  (DESIGN.md 9.1; VERDICT r2 item 1.)
+// chain?  (DESIGN.md 3.4; VERDICT r2 item 1.)
 //
 // C = A^T B for K-major fp32 operands A[K][128], B[K][128] (the engine's TN form), computed by one wave per 16 x 16
 // output tile straight from global memory (no LDS: this probe is about ROUNDING, not speed), in these modes:
