@@ -4,7 +4,8 @@ Functional restatement (explicit tensors in, tensors out; torch-CPU, autograd-ab
 
 * `init_lmc_coefficients`                           projected_lmc.py:183-201
 * parametrisations ScalarParam / UpperTriangularParam / LowerTriangularParam   :207-258
-* `LMCMixingMatrix.QR` / `.forward`                                           :864-884
+* `LMCMixingMatrix.QR` / `.forward`, bulk (:864-872, :877-882) and separately parametrised
+  `Q_plus` . `R` (`bulk=False`: :851-853, :873, :884, :963-970; loss branch :1237)
 * `ProjectedGPModel.__init__` initial values                                  :916-993
 * `.projection_matrix` :1003-1012, `.project_data` :1014-1021,
   `.full_likelihood` (task-noise Sigma) :1023-1060, `.B_tilde` :1076-1086
@@ -42,10 +43,14 @@ def svd_init(Y, n_latents, QR_form=False):
 
 def init_params(X, Y, n_latents, *, kind="rbf", nu=2.5, init_lmc_coeffs=False, BDN=True,
                 diagonal_B=False, scalar_B=False, noise_thresh=-9.0, noise_init=1e-2,
-                outputscales=False, fake_coeffs=None, eps=1e-3):
-    """Initial parameter dict of a bulk-mode ProjectedGPModel (projected_lmc.py:916-993).
+                outputscales=False, fake_coeffs=None, eps=1e-3, bulk=True, diagonal_R=False,
+                ortho_param="matrix_exp", completion=None):
+    """Initial parameter dict of a ProjectedGPModel (projected_lmc.py:916-993).
     `fake_coeffs` (p x q) replaces the reference's torch.randn draw (:955) so that
-    product and oracle can be seeded identically."""
+    product and oracle can be seeded identically.  `bulk=False` (:963-970): the values torch's
+    `register_parametrization` leaves in `original` -- -Id for the trivialised orthogonal map with `base` = Q_plus
+    completed to p x p (`completion`: the p x (p-c) block torch draws with randn for a rectangular Q_plus; any
+    completion gives the same Q_plus at initialisation), the log-diagonal right inverses for R (:224-227, :236-240)."""
     n, p = Y.shape
     q = n_latents
     d = X.shape[1]
@@ -74,11 +79,33 @@ def init_params(X, Y, n_latents, *, kind="rbf", nu=2.5, init_lmc_coeffs=False, B
         H = Q_plus @ R
     P = dict(kind=kind, nu=nu, n_tasks=p, n_latents=q, mode=mode, BDN=BDN, eps=eps,
              scalar_B=scalar_B, diagonal_B=(diagonal_B or scalar_B), noise_lb=math.exp(noise_thresh),
-             noise_thresh=noise_thresh,
-             H=H.clone(),
+             noise_thresh=noise_thresh, bulk=bulk,
              raw_lengthscale=torch.zeros(q, 1, d, dtype=dt),
              raw_outputscale=(torch.zeros(q, dtype=dt) if outputscales else None),
              raw_noise=torch.zeros(q, 1, dtype=dt))
+    if bulk:
+        P["H"] = H.clone()
+    else:
+        c = Q_plus.shape[1]
+        P.update(diagonal_R=diagonal_R, ortho_param=ortho_param)
+        if ortho_param == "householder":                                   # no trivialisation: geqrf reflectors, signed diagonal
+            A, tau = torch.geqrf(Q_plus)
+            A.diagonal().sign_()
+            A.diagonal()[tau == 0.0] *= -1
+            P["Q_plus_original"], P["Q_plus_base"] = A, None
+        else:
+            Qc = Q_plus.clone()
+            if c != p:
+                N = completion if completion is not None else torch.randn(p, p - c, dtype=dt)
+                Qc = torch.cat([Qc, N], dim=-1)
+            Qf, Rf = torch.linalg.qr(Qc)                                   # torch's _make_orthogonal
+            P["Q_plus_base"] = Qf * torch.diagonal(Rf).sgn().unsqueeze(-2)
+            negId = torch.zeros(p, c, dtype=dt)
+            negId.diagonal().fill_(-1.0)
+            P["Q_plus_original"] = negId
+        Rl = R.clone()
+        Rl.diagonal().copy_(torch.log(torch.diagonal(R)))
+        P["R_original"] = torch.diag_embed(torch.diagonal(Rl)) if diagonal_R else Rl
     if scalar_B or diagonal_B:
         P["log_B_tilde"] = math.log(noise_init) * torch.ones(p - q, dtype=dt)      # :975/:980
     else:
@@ -92,7 +119,8 @@ def init_params(X, Y, n_latents, *, kind="rbf", nu=2.5, init_lmc_coeffs=False, B
 
 
 def tensor_keys(P):
-    return [k for k, v in P.items() if torch.is_tensor(v)]
+    """The parameters (what an optimiser steps): every tensor but the fixed base of the orthogonal trivialisation (a buffer)."""
+    return [k for k, v in P.items() if torch.is_tensor(v) and k != "Q_plus_base"]
 
 
 # ----------------------------------------------------------------- constrained views
@@ -130,17 +158,72 @@ def B_tilde_inv_chol(P):
     return lower - torch.diag_embed(torch.diagonal(lower)) + torch.diag_embed(dg)
 
 
+def orthogonal_map(X, base, ortho_param="matrix_exp"):
+    """What `torch.nn.utils.parametrizations.orthogonal(lmc, name="Q_plus", orthogonal_map=ortho_param,
+    use_trivialization=(ortho_param != 'householder'))` (:963-965) evaluates for a tall or square p x c matrix --
+    third-party (torch) arithmetic the reference calls, restated from its published definition
+    (torch/nn/utils/parametrizations.py, `_Orthogonal.forward`):
+      matrix_exp / cayley: A = L - L^T with L = tril(X) padded to p x p; Q = expm(A) or (I - A/2)^-1 (I + A/2), first c columns;
+      householder: product of the reflectors in tril(X, -1), columns signed by diag(X);
+    with the trivialisation (`base` p x p, fixed at registration; `original` starts at -Id) Q <- base @ Q."""
+    n, k = X.shape
+    assert n >= k
+    if ortho_param in ("matrix_exp", "cayley"):
+        L = X.tril()
+        if n != k:
+            L = torch.cat([L, L.new_zeros(n, n - k)], dim=-1)
+        A = L - L.T
+        if ortho_param == "matrix_exp":
+            Q = torch.matrix_exp(A)
+        else:
+            Id = torch.eye(n, dtype=A.dtype)
+            Q = torch.linalg.solve(Id - 0.5 * A, Id + 0.5 * A)
+        Q = Q[:, :k]
+    else:
+        A = X.tril(diagonal=-1)
+        tau = 2.0 / (1.0 + (A * A).sum(dim=-2))
+        Q = torch.linalg.householder_product(A, tau)
+        Q = Q * torch.diagonal(X).detach().int().unsqueeze(-2)
+    if base is not None:
+        Q = base @ Q
+    return Q
+
+
+def R_param(P):
+    """The parametrised R of `bulk=False` (:966-970): PositiveDiagonalParam (:220-227, `diagonal_R`) keeps exp of the
+    diagonal of `original` and nothing else; UpperTriangularParam (:229-240) its upper triangle with exp on the diagonal."""
+    X = P["R_original"]
+    if P["diagonal_R"]:
+        return torch.diag_embed(torch.exp(torch.diagonal(X)))
+    upper = X.triu()
+    return upper - torch.diag_embed(torch.diagonal(upper)) + torch.diag_embed(torch.exp(torch.diagonal(upper)))
+
+
+def Q_plus(P):
+    """`lmc_coefficients.Q_plus` of `bulk=False`: the orthogonal parametrisation of `parametrizations.Q_plus.original`."""
+    return orthogonal_map(P["Q_plus_original"], P.get("Q_plus_base"), P.get("ortho_param", "matrix_exp"))
+
+
 def QR(P):
-    """LMCMixingMatrix.QR, bulk mode (:864-872)."""
+    """LMCMixingMatrix.QR (:864-875): bulk mode re-factors H (:865-872); otherwise (Q, R, Q_orth) are read off the
+    parametrised `Q_plus` and `R` (:873, :855-862)."""
     q = P["n_latents"]
-    Q_plus, R_padded = torch.linalg.qr(P["H"])
+    if not P.get("bulk", True):
+        Qp = Q_plus(P)
+        if P["mode"] == "Q_plus":
+            return Qp[:, :q], R_param(P), Qp[:, q:]
+        return Qp, R_param(P), Qp[:, q:]                                   # :861-862: p x 0 in mode 'Q'
+    Q_plus_, R_padded = torch.linalg.qr(P["H"])
     if P["mode"] == "Q_plus":
-        return Q_plus[:, :q], R_padded[:q, :q], Q_plus[:, q:]
-    return Q_plus, R_padded, None
+        return Q_plus_[:, :q], R_padded[:q, :q], Q_plus_[:, q:]
+    return Q_plus_, R_padded, None
 
 
 def lmc_coefficients(P):
     """LMCMixingMatrix.forward (:877-884): q x p."""
+    if not P.get("bulk", True):
+        Q, R, _ = QR(P)
+        return (Q @ R).T                                                   # :884
     if P["mode"] == "Q":
         return P["H"].T
     return P["H"][:, :P["n_latents"]].T
@@ -169,14 +252,14 @@ def B_tilde(P):
     if P["diagonal_B"]:
         return torch.diag_embed(torch.exp(log_B_tilde(P)))
     pq = P["n_tasks"] - P["n_latents"]
-    L_inv = torch.linalg.solve_triangular(B_tilde_inv_chol(P), torch.eye(pq, dtype=P["H"].dtype), upper=False)
+    L_inv = torch.linalg.solve_triangular(B_tilde_inv_chol(P), torch.eye(pq, dtype=P["raw_noise"].dtype), upper=False)
     return L_inv.T @ L_inv
 
 
 def full_noise_covariance(P):
     """Sigma (p x p) of `full_likelihood` before jitter (:1023-1060)."""
     p, q = P["n_tasks"], P["n_latents"]
-    dt = P["H"].dtype
+    dt = P["raw_noise"].dtype
     Q, R, Q_orth = QR(P)
     QRm = Q @ R
     sp = projected_noise(P)
@@ -247,7 +330,10 @@ def projection_terms(P, Y):
             root = Y @ Q_orth @ Bc
             terms[1] = -0.5 * (root * root).sum() / n
     terms[0] = -0.5 * 2 * torch.sum(root_diag)                           # :1233
-    terms[2] = -0.5 * torch.log(torch.diagonal(R) ** 2).sum()            # :1235 (bulk)
+    if P.get("bulk", True):
+        terms[2] = -0.5 * torch.log(torch.diagonal(R) ** 2).sum()        # :1235 (bulk)
+    else:
+        terms[2] = -0.5 * 2 * torch.diagonal(P["R_original"]).sum()      # :1237 (log of the diagonal IS the raw diagonal)
     const = -0.5 * (p - q) * math.log(2 * math.pi)                       # :1238
     return terms, const
 

@@ -197,7 +197,12 @@ template <class S>
 __global__ __launch_bounds__(64) void k_split_scales(int64_t n_pad, const float *__restrict__ eig_lo, float *__restrict__ sc, int64_t sc_stride) {
   const int lat = blockIdx.x;
   float *o = sc + (int64_t)lat * sc_stride;
-  if (threadIdx.x == 0) o[SC_TAG] = (float)S::NPL;               // which scheme wrote the planes of this scratch (checked by the K^-1 kernel)
+  if (threadIdx.x == 0) {
+    o[SC_TAG] = (float)S::NPL;               // which scheme wrote the planes of this scratch (checked by the K^-1 kernel)
+    // ... and the per-latent stride of this scratch in 128 x 128 blocks (exact in a float: < 2^24 blocks): a sweep that keeps its
+    // planes (with_inverse | 4) has a larger one than vd_w_planes assumes, and plmc_kinv_grad_vd_* may be handed either scratch
+    o[SC_TAG + 1] = (float)(sc_stride / ((int64_t)NB * NB));
+  }
   if constexpr (S::NPL == 3) {
     if (threadIdx.x < SC_N) o[threadIdx.x] = 1.0f;
   } else {
@@ -764,7 +769,10 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
                                  ? reinterpret_cast<unsigned short *>(reinterpret_cast<float *>(scl) + (int64_t)NB * NB) : nullptr;
   const int64_t pl_lat = strideV * (int64_t)(sizeof(T) / 2);            // latent stride in 16-bit elements
   const int64_t sc_lat = strideV * (int64_t)sizeof(T) / 4;              // ... in floats
-  const int grp_rows = (knobs().grp > 0 && knobs().grp < GMAX) ? knobs().grp : GMAX;   // block rows per group (as below)
+  // block rows per group (the dev knob PLMC_GRP; as below).  A sweep that KEEPS its planes always works in groups of GMAX:
+  // plmc_vd_blocks_keep reserves one buffer per GMAX block rows and plmc_potrs_aug_kept walks them in groups of GMAX (a
+  // smaller PLMC_GRP would write more buffers than were reserved and hand the cached substitution planes of the wrong rows)
+  const int grp_rows = (!keep && knobs().grp > 0 && knobs().grp < GMAX) ? knobs().grp : GMAX;
   // (keep: one buffer per group, behind the planes of W)
   unsigned short *const Uk0 = keep ? reinterpret_cast<unsigned short *>(reinterpret_cast<float *>(Wk) + vd_wk_blocks(n_pad, lda, 4) * (int64_t)NB * NB) : nullptr;
   auto planes = [&](int g0) -> unsigned short * {                       // buffer of the group that starts at block row g0
@@ -936,8 +944,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // G (G + 1) / 2 tile products into every group-panel strip; the chain of a group costs ~3 G small launches.
   std::vector<int> gb;                                    // group boundaries: gb[i] .. gb[i+1]
   {
-    int big = kn.grp > 0 ? kn.grp : GMAX;
-    if (big > GMAX) big = GMAX;
+    const int big = grp_rows;
     gb.push_back(0);
     for (int r = 0; r < m;) {
       int g = big;

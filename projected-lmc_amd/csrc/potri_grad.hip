@@ -212,6 +212,12 @@ __global__ __launch_bounds__(B3_NT, 2) void k_kinv_grad_bf3(int kind, int64_t n_
   Acc<float> acc0, acc1;
   acc0.zero();
   acc1.zero();
+  // planes taken over from a sweep (ws_stride > 1): the per-latent stride of that scratch is the one the sweep recorded behind
+  // its scheme tag -- plmc_vd_blocks_for blocks, or plmc_vd_blocks_keep when the sweep kept its planes (with_inverse | 4)
+  if (ws_stride > 1) {
+    ws_stride = (int64_t)wscale[VD_W_TAG + 1] * NB * NB;
+    wp_lat_stride = 2 * ws_stride;
+  }
   const unsigned short *Pl = Wp + (int64_t)lat * wp_lat_stride + b3_index<S>((int64_t)jb * NB, 0, 0, n_pad);
   b3_mainloop<S, 2, 0, B3NoPre, true>(acc0, acc1, Pl + (int64_t)ibm * NB * 8, n_pad, Pl + (int64_t)jb * NB * 8, n_pad, (int)(n_pad - (int64_t)jb * NB), lds);
   float ws = wscale[(int64_t)lat * ws_stride];

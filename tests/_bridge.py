@@ -15,11 +15,24 @@ def oracle_params(model, dtype=torch.float64):
     P = dict(kind=kind, nu=nu, n_tasks=model.n_tasks, n_latents=model.n_latents,
              mode=model.lmc_coefficients.mode, BDN=not hasattr(model, "M"), eps=model.eps,
              scalar_B=model.scalar_B, diagonal_B=model.diagonal_B, noise_lb=lb, noise_thresh=math.log(lb),
-             H=sd["lmc_coefficients.H"],
+             bulk=model.lmc_coefficients.bulk,
              raw_noise=sd["likelihood.noise_covar.raw_noise"],
              raw_lengthscale=sd["covar_module.base_kernel.raw_lengthscale" if hasattr(cm, "base_kernel")
                                 else "covar_module.raw_lengthscale"],
              raw_outputscale=sd.get("covar_module.raw_outputscale"))
+    if model.lmc_coefficients.bulk:
+        P["H"] = sd["lmc_coefficients.H"]
+    else:
+        # bulk=False (projected_lmc.py:963-970): torch's orthogonal parametrisation of Q_plus (original + the fixed base of its
+        # trivialisation) and the parametrised R
+        from torch.nn.utils import parametrize
+        lmc = model.lmc_coefficients
+        orth = lmc.parametrizations.Q_plus[0]
+        P["Q_plus_original"] = sd["lmc_coefficients.parametrizations.Q_plus.original"]
+        P["Q_plus_base"] = sd.get("lmc_coefficients.parametrizations.Q_plus.0.base")
+        P["ortho_param"] = orth.orthogonal_map.name
+        P["R_original"] = sd["lmc_coefficients.parametrizations.R.original"]
+        P["diagonal_R"] = type(lmc.parametrizations.R[0]).__name__ == "PositiveDiagonalParam"
     if "parametrizations.log_B_tilde.original" in sd:
         P["log_B_tilde"] = sd["parametrizations.log_B_tilde.original"]
     elif "log_B_tilde" in sd:
@@ -34,7 +47,8 @@ def oracle_params(model, dtype=torch.float64):
 # product parameter name -> oracle dict key
 def param_map(model):
     cm = model.covar_module
-    m = {"lmc_coefficients.H": "H", "likelihood.noise_covar.raw_noise": "raw_noise", "M": "M",
+    m = {"lmc_coefficients.H": "H", "lmc_coefficients.parametrizations.Q_plus.original": "Q_plus_original",
+         "lmc_coefficients.parametrizations.R.original": "R_original", "likelihood.noise_covar.raw_noise": "raw_noise", "M": "M",
          "parametrizations.log_B_tilde.original": "log_B_tilde", "log_B_tilde": "log_B_tilde",
          "parametrizations.B_tilde_inv_chol.original": "B_tilde_inv_chol_raw"}
     if hasattr(cm, "base_kernel"):

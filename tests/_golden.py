@@ -5,11 +5,13 @@ import warnings
 
 import torch
 
-PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "projected_v1.json")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PATH = os.path.join(GOLDEN, "projected_v1.json")
+PATHS = [PATH, os.path.join(GOLDEN, "projected_nonbulk_v1.json")]      # round 4: bulk=False cases in a file of their own
 
 
 def cases(kind):
-    return [c for c in json.load(open(PATH))["cases"] if c["kind"] == kind]
+    return [c for path in PATHS for c in json.load(open(path))["cases"] if c["kind"] == kind]
 
 
 def T(x):
@@ -28,4 +30,7 @@ def build_projected(plmc, c):
     with torch.no_grad():
         for k, v in c["params"].items():
             named[k].copy_(T(v).reshape(named[k].shape))
+        bufs = dict(m.named_buffers())
+        for k, v in c.get("buffers", {}).items():
+            bufs[k].copy_(T(v).reshape(bufs[k].shape))
     return m, X, Y

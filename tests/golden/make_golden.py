@@ -25,6 +25,9 @@ VARIANTS = {
     "PLMC": dict(BDN=False, diagonal_B=False, scalar_B=False),
     "PLMC_fast": dict(BDN=True, diagonal_B=True, scalar_B=True),
     "PLMC_diagB": dict(BDN=False, diagonal_B=True, scalar_B=False),
+    # bulk=False (projected_lmc.py:963-970): Q_plus orthogonally parametrised, R parametrised; "oilmm" = realdata_experiments.py:107-111
+    "oilmm_nonbulk": dict(BDN=True, diagonal_B=True, scalar_B=True, diagonal_R=True, bulk=False),
+    "PLMC_nonbulk": dict(BDN=False, diagonal_B=False, scalar_B=False, bulk=False),
 }
 
 
@@ -56,6 +59,9 @@ def projected_case(name, variant, kernel, oscale, n, d, p, q, ns, seed):
     return dict(name=name, kind="projected", variant=variant, ctor=VARIANTS[variant], kernel=kernel, outputscales=oscale,
                 n_tasks=p, n_latents=q, X=tolist(X), Y=tolist(Y), Xs=tolist(Xs),
                 params={k: tolist(v) for k, v in m.named_parameters()},
+                # buffers that are not a function of the constructor arguments: the base of the orthogonal trivialisation
+                # (torch completes a rectangular Q_plus with a random block)
+                buffers={k: tolist(v) for k, v in m.named_buffers() if k.endswith(".base")},
                 loss=float(loss.detach()), grads=grads, pred_mean=tolist(mean),
                 pred_var=tolist(torch.diagonal(cov).reshape(ns, p)), pred_var_observed=tolist(var_obs))
 
@@ -95,5 +101,14 @@ if __name__ == "__main__":
         svd_case(600),
     ]
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "projected_v1.json")
-    json.dump(dict(version=1, generator="tests/golden/make_golden.py", cases=cases), open(out, "w"))
-    print("wrote", out, os.path.getsize(out), "bytes")
+    if "--nonbulk-only" not in sys.argv:
+        json.dump(dict(version=1, generator="tests/golden/make_golden.py", cases=cases), open(out, "w"))
+        print("wrote", out, os.path.getsize(out), "bytes")
+    # round 4: the separately parametrised mixing matrix (bulk=False), in a file of its own so that v1 stays byte-identical
+    cases2 = [
+        projected_case("oilmm_nonbulk_matern", "oilmm_nonbulk", "MaternKernel", False, 88, 3, 5, 2, 6, 700),
+        projected_case("plmc_nonbulk_rbf_outputscale", "PLMC_nonbulk", "RBFKernel", True, 80, 2, 4, 2, 5, 800),
+    ]
+    out2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "projected_nonbulk_v1.json")
+    json.dump(dict(version=1, generator="tests/golden/make_golden.py", cases=cases2), open(out2, "w"))
+    print("wrote", out2, os.path.getsize(out2), "bytes")

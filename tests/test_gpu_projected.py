@@ -78,6 +78,65 @@ def test_training_loss_and_all_gradients(plmc, name, kernel, oscale):
         assert abs(float(a) - float(b)) < 1e-9 * max(1.0, abs(float(b)))
 
 
+NONBULK = {
+    # realdata_experiments.py:107-111, the OILMM run: bulk=False, orthogonally parametrised Q (p x q), diagonal positive R
+    "oilmm": dict(BDN=True, diagonal_B=True, scalar_B=True, diagonal_R=True),
+    "PLMC": dict(BDN=False, diagonal_B=False, scalar_B=False),                       # Q_plus p x p, upper-triangular R
+    "BDN_diagB_cayley": dict(BDN=True, diagonal_B=True, scalar_B=False, ortho_param="cayley"),
+}
+
+
+@pytest.mark.parametrize("name", list(NONBULK))
+@pytest.mark.parametrize("kernel", ["MaternKernel", "RBFKernel"])
+def test_separately_parametrised_mixing_matrix_loss_and_all_gradients(plmc, name, kernel):
+    """`bulk=False` (projected_lmc.py:851-853, :873, :884, :963-970; loss branch :1237): loss, every gradient (incl. the raw
+    orthogonal and triangular parameters), the stored projection terms and the eval-mode task posterior against the oracle."""
+    n, d, p, q = 333, 3, 6, 2
+    X, Y = _data(n, d, p, seed=12)
+    torch.manual_seed(6)
+    m = _model(plmc, X, Y, q, getattr(plmc, kernel), init_lmc_coeffs=True, bulk=False, **NONBULK[name])
+    assert not m.lmc_coefficients.bulk
+    m = perturb_(m.double())
+    P = oracle_params(m)
+    assert not P["bulk"] and P["diagonal_R"] == bool(NONBULK[name].get("diagonal_R", False))
+    for k in pj.tensor_keys(P):
+        P[k].requires_grad_(True)
+    ref = -pj.projected_mll(P, X, Y)
+    ref.backward()
+
+    m = m.to(DEV)
+    Xd, Yd = X.to(DEV), Y.to(DEV)
+    m.train()
+    m.likelihood.train()
+    mll = plmc.ProjectedLMCmll(m.likelihood, m)
+    loss = -mll(m(Xd), Yd)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) < 1e-9 * abs(float(ref)), (float(loss), float(ref))
+    pm = param_map(m)
+    names = [pname for pname, _ in m.named_parameters()]
+    assert "lmc_coefficients.parametrizations.Q_plus.original" in names and "lmc_coefficients.parametrizations.R.original" in names
+    for pname, prm in m.named_parameters():
+        g_ref = P[pm[pname]].grad
+        assert prm.grad is not None, pname
+        assert torch.allclose(prm.grad.cpu(), g_ref, rtol=2e-6, atol=1e-8), (pname, prm.grad.cpu(), g_ref)
+    terms, _ = pj.projection_terms(P, Y)
+    for a, b in zip(mll.proj_term_list, terms):
+        assert abs(float(a) - float(b)) < 1e-9 * max(1.0, abs(float(b)))
+    # eval mode: the task posterior mixes with H = Q R of the parametrised pair (:884)
+    Pd = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in P.items()}
+    Xs = 2 * torch.rand(48, d, dtype=torch.float64) - 1
+    mean_ref, cov_ref = pj.task_posterior(Pd, X, Y, Xs)
+    _, var_obs_ref = pj.observed_posterior(Pd, X, Y, Xs)
+    m.eval()
+    m.likelihood.eval()
+    with torch.no_grad():
+        dist = m(Xs.to(DEV))
+        obs = m.full_likelihood()(dist)
+    assert torch.allclose(dist.mean.cpu(), mean_ref, rtol=1e-8, atol=1e-10)
+    assert torch.allclose(dist.variance.cpu(), torch.diagonal(cov_ref).reshape(48, p), rtol=1e-7, atol=1e-10)
+    assert torch.allclose(obs.variance.cpu(), var_obs_ref, rtol=1e-7, atol=1e-10)
+
+
 @pytest.mark.parametrize("name", ["PLMC", "PLMC_fast"])
 def test_eval_mode_task_posterior(plmc, name):
     n, d, p, q, ns = 200, 2, 5, 2, 64

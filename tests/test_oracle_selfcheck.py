@@ -118,6 +118,40 @@ def test_projected_mll_equals_dense_lmc_density(name, kind, init):
     assert torch.allclose(mll * X.shape[0], dense, rtol=1e-9), (float(mll * 40), float(dense))
 
 
+NONBULK = {
+    # realdata_experiments.py:107-111: the OILMM configuration (orthogonal Q, diagonal R, scalar B, block-diagonal noise)
+    "oilmm": dict(BDN=True, diagonal_B=True, scalar_B=True, diagonal_R=True),
+    "PLMC": dict(BDN=False, diagonal_B=False, scalar_B=False),
+    "BDN_diagB_cayley": dict(BDN=True, diagonal_B=True, scalar_B=False, ortho_param="cayley"),
+    "PLMC_householder": dict(BDN=False, diagonal_B=True, scalar_B=False, ortho_param="householder"),
+}
+
+
+@pytest.mark.parametrize("name", list(NONBULK))
+@pytest.mark.parametrize("init", [False, True])
+def test_projected_mll_equals_dense_lmc_density_with_separately_parametrised_Q_and_R(name, init):
+    """The same identity for `bulk=False` (projected_lmc.py:851-853, :873, :884, :963-970 and the loss branch :1237): Q_plus
+    through torch's orthogonal parametrisation, R diagonal-positive or upper-triangular with exp on the diagonal."""
+    X, Y = _data(n=40, d=2, p=5)
+    fc = torch.randn(5, 2, generator=torch.Generator().manual_seed(3))
+    P = pj.init_params(X, Y, 2, kind="matern", init_lmc_coeffs=init, fake_coeffs=fc, bulk=False, **NONBULK[name])
+    # at initialisation the parametrised pair reproduces the bulk matrix H = Q R of the same draw
+    Pb = pj.init_params(X, Y, 2, kind="matern", init_lmc_coeffs=init, fake_coeffs=fc,
+                        **{k: v for k, v in NONBULK[name].items() if k not in ("diagonal_R", "ortho_param")})
+    assert torch.allclose(pj.lmc_coefficients(P), pj.lmc_coefficients(Pb), atol=1e-12)
+    assert torch.allclose(pj.projected_mll(P, X, Y), pj.projected_mll(Pb, X, Y), rtol=1e-10)
+    P = _perturb(P)
+    if P["ortho_param"] == "householder":                      # the signed diagonal is not a free parameter
+        P["Q_plus_original"].diagonal().copy_(torch.sign(P["Q_plus_original"].diagonal()))
+    Q, R, Q_orth = pj.QR(P)
+    assert torch.allclose(Q.T @ Q, torch.eye(2), atol=1e-12)
+    if Q_orth.numel():
+        assert torch.allclose(Q.T @ Q_orth, torch.zeros(2, 3), atol=1e-12)
+    mll = pj.projected_mll(P, X, Y)
+    dense = pj.dense_lmc_log_density(P, X, Y)
+    assert torch.allclose(mll * X.shape[0], dense, rtol=1e-9), (float(mll * 40), float(dense))
+
+
 @pytest.mark.parametrize("name", ["PLMC", "PLMC_fast", "BDN_diagB"])
 def test_p_equals_q_edge(name):
     X, Y = _data(n=30, d=2, p=3)
