@@ -84,6 +84,66 @@ def test_cached_substitution_on_the_split_engine_over_three_groups_fp32():
     assert (o1.variance - o1b.variance).abs().max() < 5e-5 * max(1.0, float(o1.variance.abs().max()))
 
 
+@pytest.mark.parametrize("grp", ["4", "3"])
+def test_cached_substitution_ignores_the_group_size_knob(grp):
+    """the kept-plane buffers are reserved and later walked in groups of 8 block rows; with the dev knob PLMC_GRP < 8 the
+    caching sweep used to write one buffer per SMALLER group (past the reserved room) and the cached substitution read planes of
+    the wrong rows.  A sweep that keeps its planes now always works in groups of 8: same posterior under the knob, first call ==
+    cached call == oracle."""
+    from oracle import projected as oproj
+    from projectedlmc import _hip
+    from _bridge import oracle_params
+    m, X, Y = _model(n=2600, d=4, p=4, q=2, seed=3, dtype=torch.float32, BDN=False)
+    P = oracle_params(m)
+    g = torch.Generator().manual_seed(8)
+    Xs = 2 * torch.rand(333, 4, generator=g, dtype=torch.float32) - 1
+    m = m.to(DEV).eval()
+    with _hip.knob("PLMC_GRP", grp), torch.no_grad():
+        o1 = m(Xs.to(DEV))
+        c = m._prediction_cache()
+        assert c.ws is not None and c.ws.keep_planes and c.ws.m == 21
+        o1b = m(Xs.to(DEV))
+        assert (c.hits, c.misses) == (1, 1)
+        torch.cuda.synchronize()
+    mean, cov = oproj.task_posterior(P, X.double(), Y.double(), Xs.double())
+    var = torch.diagonal(cov).reshape(Xs.shape[0], -1)
+    for got in (o1, o1b):
+        assert (got.mean.cpu().double() - mean).abs().max() < 2e-4 * max(1.0, float(mean.abs().max()))
+        assert (got.variance.cpu().double() - var).abs().max() < 2e-4 * max(1.0, float(var.abs().max()))
+    assert (o1.mean - o1b.mean).abs().max() < 5e-5 * max(1.0, float(o1.mean.abs().max()))
+
+
+def test_kinv_grad_reads_the_planes_of_a_sweep_that_kept_its_planes():
+    """include/plmc.h allows plmc_kinv_grad_vd_* behind any sweep with the inverse factor.  A sweep that keeps its planes
+    (with_inverse | 4) has a larger per-latent scratch stride; the K^-1 kernel takes the stride the sweep recorded in its scale
+    block: gradients of q = 3 latents from a kept-plane scratch are bit-identical to those from a plain one."""
+    from projectedlmc import _hip, _engine
+    L = _hip.lib()
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(2)
+    n, d, q = 1500, 5, 3
+    dt = torch.float32
+    X = (2 * torch.rand(n, d, generator=g) - 1).to(dev)
+    ell = (0.5 + torch.rand(q, d, generator=g)).to(dev)
+    noise = torch.tensor([0.05, 0.2, 0.01]).to(dev)
+    y = torch.randn(q, n, generator=g).to(dev)
+    grads = []
+    for keep in (False, True):
+        ws = _engine.Workspace(n, q, 1, dt, dev, with_inverse=True, keep_planes=keep)
+        st = _hip.stream_ptr(dev)
+        _engine.factorize("matern52", X, ell, None, noise, y.reshape(q, 1, n), ws)
+        L.call("plmc_extract_col", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, 0, _hip.ptr(ws.z), _hip.ptr(ws.quad), q, st)
+        L.call("plmc_wt_matvec", dt, _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.z), _hip.ptr(ws.alpha), q, st)
+        grad = torch.empty(q, d + 2, dtype=torch.float64, device=dev)
+        L.call("plmc_kinv_grad_vd", dt, _hip.KIND["matern52"], _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.alpha), _hip.ptr(X), n, d,
+               _hip.ptr(ell), None, _hip.ptr(grad), None, 0, 0, None, _hip.ptr(ws.partials), q, _hip.ptr(noise), _hip.ptr(ws.Vd), st)
+        torch.cuda.synchronize()
+        assert int(ws.info.abs().max()) == 0
+        grads.append(grad.cpu())
+    assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0
+    assert torch.equal(grads[0], grads[1]), (grads[0] - grads[1]).abs().max()
+
+
 def test_cache_is_dropped_when_the_model_changes():
     from oracle import projected as oproj
     from _bridge import oracle_params

@@ -14,6 +14,14 @@
 //            alone (round-to-nearest would give ~sqrt(K/32) 2^-25 |sum|; truncation ~ (K/32) 2^-24 |sum|).
 // Errors are against an fp64 host product: max |err| / max |C| and rms err / rms C, for K = 1024 (a trailing update of
 // the sweep) and K = 8192 (the long products of K^-1 = W^T W), normal and wide-range (log-normal scaled) data.
+// Round 4: the fp16 modes scale each operand FAMILY as the product does (csrc/bf3_engine.hpp b3_scale_for: the power of two that
+// puts the largest magnitude of A resp. B at 2^13, undone exactly at the end) -- round 3's probe fed them unscaled data, whose
+// wide-range case overflowed fp16 (the nan rows of profiles/r03_split_numerics.txt) -- and two COMPONENTWISE figures are reported:
+//   cw  = max_ij |err_ij| / sum_k |a_ki b_kj|       (what the a-priori bound below bounds), and
+//   rel = max |err_ij| / |C_ij| over the entries with |C_ij| >= 2^-20 max |C|.
+// A-priori (K-term products, u = 2^-24):  fp32 chain  cw <= K u;   fp16x2 / 3 products / 2 levels
+//   cw <= 2 * 2^-23 (each operand rounded to 22 bits) + 2^-22 (the dropped h1.h1 product) + (K / 32 + 2) u (roundings of the level-0
+//   sum, one per MFMA) -- for operands within 2^-27 of their family's bound; smaller ones lose bits (h0 goes subnormal).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/split_numerics_probe tools/split_numerics_probe.hip
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -59,7 +67,8 @@ __device__ __forceinline__ void split_h(const float (&x)[8], f16x8 &h, f16x8 &m,
 
 // one wave per 16 x 16 tile; grid (8, 8); C[128][128]
 template <int MODE>
-__global__ __launch_bounds__(64) void k_probe(const float *__restrict__ A, const float *__restrict__ B, int K, float *__restrict__ C, float *__restrict__ Chh) {
+__global__ __launch_bounds__(64) void k_probe(const float *__restrict__ A, const float *__restrict__ B, int K, float *__restrict__ C, float *__restrict__ Chh,
+                                              float sA, float sB) {
   const int lane = threadIdx.x, ti = blockIdx.y, tj = blockIdx.x;
   const int fr = lane & 15, fg = lane >> 4;
   f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
@@ -78,6 +87,8 @@ __global__ __launch_bounds__(64) void k_probe(const float *__restrict__ A, const
       }
       if constexpr (MODE == M_H6_3 || MODE == M_H6_2 || MODE == M_H3_2 || MODE == M_H4_2) {
         f16x8 ah, am, al, bh, bm, bl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xa[j] *= sA; xb[j] *= sB; }      // the family scales of the product (powers of two: exact)
         split_h(xa, ah, am, al);
         split_h(xb, bh, bm, bl);
 #define MMH(x, y, c) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0)
@@ -121,8 +132,8 @@ __global__ __launch_bounds__(64) void k_probe(const float *__restrict__ A, const
     }
   }
   f32x4 r;
-  if constexpr (MODE == M_H6_3) r = acc0 + (acc1 + acc2 * (1.0f / 2048.0f)) * (1.0f / 2048.0f);
-  else if constexpr (MODE == M_H6_2 || MODE == M_H3_2 || MODE == M_H4_2) r = acc0 + acc1 * (1.0f / 2048.0f);
+  if constexpr (MODE == M_H6_3) r = (acc0 + (acc1 + acc2 * (1.0f / 2048.0f)) * (1.0f / 2048.0f)) * (1.0f / (sA * sB));
+  else if constexpr (MODE == M_H6_2 || MODE == M_H3_2 || MODE == M_H4_2) r = (acc0 + acc1 * (1.0f / 2048.0f)) * (1.0f / (sA * sB));
   else r = acc0 + (acc1 + acc2);
   // C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg
 #pragma unroll
@@ -139,8 +150,13 @@ static float bf16_round(float x) {   // round to nearest even to bf16, as the de
   return y;
 }
 
-template <int MODE> static void launch(const float *A, const float *B, int K, float *C) {
-  hipLaunchKernelGGL((k_probe<MODE>), dim3(8, 8), dim3(64), 0, 0, A, B, K, C, (float *)nullptr);
+template <int MODE> static void launch(const float *A, const float *B, int K, float *C, float sA, float sB) {
+  hipLaunchKernelGGL((k_probe<MODE>), dim3(8, 8), dim3(64), 0, 0, A, B, K, C, (float *)nullptr, sA, sB);
+}
+static float scale_for(float bound) {       // csrc/bf3_engine.hpp b3_scale_for
+  int e;
+  (void)frexpf(bound, &e);
+  return ldexpf(1.0f, 13 - e);
 }
 
 int main() {
@@ -199,15 +215,27 @@ int main() {
         if (dist == 2) { a = fabs(a) + 0.5; b = fabs(b) + 0.5; }                   // one sign: sums grow like K, no cancellation
         A[i] = (float)a; B[i] = (float)b;
       }
-      std::vector<double> ref((size_t)128 * 128, 0.0), refhh((size_t)128 * 128, 0.0);
+      std::vector<double> ref((size_t)128 * 128, 0.0), refhh((size_t)128 * 128, 0.0), refabs((size_t)128 * 128, 0.0);
       for (int k = 0; k < K; ++k)
         for (int i = 0; i < 128; ++i) {
           const double a = A[(size_t)k * 128 + i], ah = bf16_round(A[(size_t)k * 128 + i]);
           for (int j = 0; j < 128; ++j) {
             ref[(size_t)i * 128 + j] += a * (double)B[(size_t)k * 128 + j];
+            refabs[(size_t)i * 128 + j] += fabs(a * (double)B[(size_t)k * 128 + j]);
             refhh[(size_t)i * 128 + j] += ah * (double)bf16_round(B[(size_t)k * 128 + j]);
           }
         }
+      float amaxA = 0, amaxB = 0;
+      for (auto v : A) amaxA = fmaxf(amaxA, fabsf(v));
+      for (auto v : B) amaxB = fmaxf(amaxB, fabsf(v));
+      const float sA = scale_for(amaxA), sB = scale_for(amaxB);
+      {   // how much of the data sits below 2^-27 of its family's bound (h0 subnormal: bits are lost)
+        size_t lowA = 0, lowB = 0;
+        for (auto v : A) lowA += fabsf(v) * sA < ldexpf(1.0f, -14) && v != 0.0f;
+        for (auto v : B) lowB += fabsf(v) * sB < ldexpf(1.0f, -14) && v != 0.0f;
+        printf("   family bounds: max|A| %.3e (scale 2^%d), max|B| %.3e (scale 2^%d); entries below 2^-27 of the bound: %.3f %% / %.3f %%\n", amaxA,
+               (int)log2f(sA), amaxB, (int)log2f(sB), 100.0 * lowA / A.size(), 100.0 * lowB / B.size());
+      }
       float *dA, *dB, *dC;
       CK(hipMalloc(&dA, A.size() * 4)); CK(hipMalloc(&dB, B.size() * 4)); CK(hipMalloc(&dC, 128 * 128 * 4));
       CK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
@@ -217,24 +245,27 @@ int main() {
       double e_f32_max = 0, e_f32_rms = 0;
       for (int mode = 0; mode < M_COUNT; ++mode) {
         switch (mode) {
-#define CASE(M) case M: launch<M>(dA, dB, K, dC); break;
+#define CASE(M) case M: launch<M>(dA, dB, K, dC, sA, sB); break;
           CASE(M_F32) CASE(M_B6_1) CASE(M_B6_2) CASE(M_B6_3) CASE(M_B8_1) CASE(M_B8_2) CASE(M_B8_3) CASE(M_B9_2) CASE(M_B9_3) CASE(M_H6_3) CASE(M_H6_2) CASE(M_HH) CASE(M_B3_1) CASE(M_H3_2) CASE(M_H4_2)
 #undef CASE
         }
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
         const std::vector<double> &R = mode == M_HH ? refhh : ref;
-        double emax = 0, cmax = 0, e2 = 0, c2 = 0, bias = 0;
+        double emax = 0, cmax = 0, e2 = 0, c2 = 0, bias = 0, cw = 0, rel = 0;
+        for (size_t i = 0; i < C.size(); ++i) cmax = fmax(cmax, fabs(R[i]));
         for (size_t i = 0; i < C.size(); ++i) {
           const double e = (double)C[i] - R[i];
-          emax = fmax(emax, fabs(e)); cmax = fmax(cmax, fabs(R[i]));
+          emax = fmax(emax, fabs(e));
           e2 += e * e; c2 += R[i] * R[i];
           bias += e * (R[i] >= 0 ? 1.0 : -1.0);      // > 0: magnitudes too large; < 0: truncation toward zero
+          if (mode != M_HH) cw = fmax(cw, fabs(e) / refabs[i]);
+          if (fabs(R[i]) >= ldexp(cmax, -20)) rel = fmax(rel, fabs(e) / fabs(R[i]));
         }
         const double rmax = emax / cmax, rrms = sqrt(e2 / c2);
         if (mode == M_F32) { e_f32_max = rmax; e_f32_rms = rrms; }
-        printf("  %-22s max|err|/max|C| %.3e (%.2fx f32)   rms err/rms C %.3e (%.2fx f32)   signed mean err/rms C %+.2e\n", mode_name[mode], rmax,
-               rmax / e_f32_max, rrms, rrms / e_f32_rms, bias / C.size() / sqrt(c2 / C.size()));
+        printf("  %-22s max|err|/max|C| %.3e (%.2fx f32)   rms err/rms C %.3e (%.2fx f32)   signed mean err/rms C %+.2e   cw %.3e   rel(>=2^-20 max) %.3e\n",
+               mode_name[mode], rmax, rmax / e_f32_max, rrms, rrms / e_f32_rms, bias / C.size() / sqrt(c2 / C.size()), cw, rel);
       }
       CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
     }
