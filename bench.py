@@ -156,25 +156,24 @@ def oracle_latent(X, ell, noise, ytil):
     return float(lp), torch.cat([ge.reshape(-1), gn.reshape(-1), gy.reshape(-1)])
 
 
-def cpu_baseline(X, Y, model_cpu_state, n_latents, budget_latents=4):
-    """The oracle ("port": plain torch-CPU restatement, all host threads) timed on a bounded sample
-    of the same step: `budget_latents` of the q latent MLL+gradient evaluations at full n.
-    iters/sec = 1 / (q * t_per_latent)."""
+def cpu_baseline(X, Y, P, n_latents):
+    """The oracle ("port": plain torch-CPU restatement, all host threads) timed on ONE full training step of the same
+    workload -- the loop body of experiments.py:264-273: projection, the q latent exact-GP MLL+gradient evaluations at full n
+    (fp32 dense Cholesky + cholesky_inverse, analytic gradient), projection terms, backward, AdamW step
+    (oracle/cpu_step.py projected_step) -- after one untimed latent evaluation (thread pools, page-in).  iters/sec = 1 / t_step."""
     from oracle import cpu_step
+    from oracle import projected as pj
     torch.set_num_threads(host_cores())
-    ell, noise, ytil = model_cpu_state
     n = X.shape[0]
-    ts = []
-    for i in range(budget_latents + 1):          # first pass = warm-up (thread pools, page-in)
-        j = i % n_latents
-        t0 = time.time()
-        lp, *_ = cpu_step.latent_step("matern", X, ell[j], noise[j], ytil[j], nu=2.5)
-        ts.append(time.time() - t0)
-    t = sum(ts[1:]) / len(ts[1:]) if len(ts) > 1 else ts[0]          # mean over the sampled latents (~10 s of CPU work)
-    return dict(value=1.0 / (n_latents * t), unit="iters/sec", cores=torch.get_num_threads(), kind="port",
-                sample="%d of %d latent exact-GP MLL+gradient evaluations at n=%d (fp32 dense Cholesky + inverse, "
-                       "torch CPU), scaled to the full %d-latent step; %.1f s per latent" % (
-                           budget_latents, n_latents, n, n_latents, t))
+    with torch.no_grad():
+        cpu_step.latent_step(P["kind"], X, pj.lengthscale(P)[0], pj.projected_noise(P)[0], pj.project_data(P, Y)[0], nu=P["nu"])
+    t0 = time.time()
+    loss, _ = cpu_step.projected_step(P, X, Y)
+    t = time.time() - t0
+    return dict(value=1.0 / t, unit="iters/sec", cores=torch.get_num_threads(), kind="port",
+                sample="one full training step (projection + %d latent exact-GP MLL+gradient evaluations at n=%d, fp32 dense "
+                       "Cholesky + inverse with the analytic gradient + projection terms + backward + AdamW; torch CPU) after one "
+                       "untimed latent evaluation: %.1f s; loss %.6f" % (n_latents, n, t, loss))
 
 
 def self_launch(n_ranks):
@@ -254,6 +253,10 @@ def main():
                                       kernel_type=plmc.MaternKernel, init_lmc_coeffs=True,
                                       latent_shard=(rank, world) if world > 1 else None, **kw)
     # initial state for the CPU baseline / log-lik check (before moving to the device)
+    cpu_params = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import bridge
+        cpu_params = bridge.oracle_params(model, dtype=dt)                 # raw parameters of the initial model, oracle form
     with torch.no_grad():
         cpu_state = (model.covar_module.lengthscale.reshape(q, d).clone(), model.projected_noise().clone(),
                      model.project_data(Y).clone())
@@ -468,8 +471,8 @@ def main():
                                          "exceed it: its bulk products run on the bf16 matrix cores)" % p32}
         note("%.2f ms/step on %d GPU(s)" % (1e3 * elapsed / args.steps, world))
         if world == 1 and not args.no_cpu_baseline:
-            note("timing the CPU oracle on %d host cores (bounded sample: 4 of %d latents) ..." % (host_cores(), q))
-            cb = cpu_baseline(X, Y, cpu_state, q)
+            note("timing the CPU oracle on %d host cores (one full step of the same workload) ..." % host_cores())
+            cb = cpu_baseline(X, Y, cpu_params, q)
             res["cpu_baseline"] = cb
             res["speedup_vs_cpu"] = its / cb["value"]
             note("fp64 oracle at the %d accuracy checkpoints ..." % len(checkpoints))

@@ -57,3 +57,39 @@ def latent_logp(kind, X, ell, noise, y, nu=2.5, outputscale=None, chunk=512):
     del K
     z = torch.linalg.solve_triangular(L, y[:, None], upper=False)[:, 0]
     return -0.5 * (z @ z + 2.0 * torch.log(torch.diagonal(L)).sum() + n * gm.LOG2PI)
+
+
+def projected_step(P, X, Y, opt=None, lr=1e-2):
+    """ONE full training step of the projected model on the CPU -- the loop body of experiments.py:264-273: zero_grad ->
+    model(X) -> -mll -> backward -> AdamW step -- for bench.py's `cpu_baseline` leg ("port").
+    The loss is oracle.projected.projected_mll (projected_lmc.py:1178-1241); the q latent exact-GP terms (:1200-1201) use
+    `latent_step` above (dense Cholesky + cholesky_inverse, analytic gradient: the cheapest exact CPU form -- torch autograd
+    through torch.linalg.cholesky is ~3 x slower) and their gradients are pushed into the autograd graph of the
+    projection (:1014-1021) and of the constraint transforms; the projection terms (:1205-1240) go through autograd.
+    P: oracle parameter dict whose tensors are leaves; returns (loss, optimiser)."""
+    from . import projected as pj
+    keys = pj.tensor_keys(P)
+    for k in keys:
+        P[k].requires_grad_(True)
+    if opt is None:
+        opt = torch.optim.AdamW([P[k] for k in keys], lr=lr)
+    opt.zero_grad()
+    n = X.shape[0]
+    q = P["n_latents"]
+    kind = P["kind"]
+    ytil = pj.project_data(P, Y)                                          # q x n, in the graph
+    ell, noise, osc = pj.lengthscale(P), pj.projected_noise(P), pj.outputscale(P)
+    assert osc is None, "latent_step returns no output-scale gradient: the baseline workload has outputscales=False"
+    lps, g_ell, g_nz, g_y = [], [], [], []
+    with torch.no_grad():
+        for i in range(q):
+            lp, ge, gn, gy = latent_step(kind, X, ell[i], noise[i], ytil[i], nu=P["nu"], outputscale=None if osc is None else osc[i])
+            lps.append(lp); g_ell.append(ge); g_nz.append(gn); g_y.append(gy)
+    # d(-sum lp / n): the analytic latent gradients enter the graph at (lengthscale, noise, projected targets)
+    torch.autograd.backward([ell, noise, ytil], [-torch.stack(g_ell) / n, -torch.stack(g_nz).reshape(noise.shape) / n, -torch.stack(g_y) / n])
+    terms, const = pj.projection_terms(P, Y)
+    proj = sum(terms) + const
+    (-proj).backward()
+    opt.step()
+    loss = -(torch.stack(lps).sum() / n + proj.detach())
+    return float(loss), opt
