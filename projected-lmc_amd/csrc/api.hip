@@ -42,6 +42,8 @@ static void load_knobs() {
   g_knobs.split = getenv("PLMC_SPLIT") ? atoi(getenv("PLMC_SPLIT")) : 2;     // fp32 entry points only
   if (g_knobs.split != 0 && g_knobs.split != 3) g_knobs.split = 2;
   g_knobs.bulk_streams = getenv("PLMC_BULK_STREAMS") ? atoi(getenv("PLMC_BULK_STREAMS")) : 2;
+  g_knobs.chain = getenv("PLMC_CHAIN") ? atoi(getenv("PLMC_CHAIN")) : 1;
+  g_knobs.chain_nw = getenv("PLMC_CHAIN_NW") ? atoi(getenv("PLMC_CHAIN_NW")) : 0;
   g_knobs_loaded = true;
 }
 const Knobs &knobs() {

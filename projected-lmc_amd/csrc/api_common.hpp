@@ -55,6 +55,8 @@ struct Knobs {
                        // everywhere; 3 = three bf16 planes, six products (bf3_engine.hpp SplitB3); 2 (default) = two fp16 planes, three
                        // products (SplitH2) where the caller gives eigenvalue bounds (plmc_*_ex_f32), SplitB3 otherwise
   int bulk_streams;    // PLMC_BULK_STREAMS: 2 = group panel + head rows on their own helper stream beside the tail, 1 = in front of the tail on the caller's stream
+  int chain;           // PLMC_CHAIN: 1 (default) = the chain of a group as one resident launch (k_chain), 0 = three launches per block row
+  int chain_nw;        // PLMC_CHAIN_NW: workgroups per latent of the resident chain (0 = by the number of latents)
   int kinv_order;      // PLMC_KINV_ORDER: tile order of the gradient kernel (0 XCD-dealt, 1 grid, 4 longest first, 5 = 4 + general epilogue)
 };
 const Knobs &knobs();

@@ -114,23 +114,36 @@ __device__ __forceinline__ void factor16(const T *S, T *ub, T *wb, int lane) {
 //   then every worker stores its finished row-s tile to global memory (off the critical path).
 // Result: U_kk (upper) in place, Vd = W_kk^T and (optionally) W_kk: lower / diagonal tiles only -- the
 // caller zeroes the other tiles once per sweep.  log det and the pivot check are done by k_logdet.
-template <typename T, int DBG = 0, int NT = DIAG_NT>
-__global__ __launch_bounds__(NT) void k_diag(T *A, int64_t lda, int64_t strideA, int kblk, T *__restrict__ Vd,
-                                             int64_t strideV, T *Wout, int64_t ldw, int64_t strideW) {
-  static_assert(NT == 512, "tile ownership is laid out for 8 waves");
+// SC1 forms of the body's global accesses, for a caller whose inputs / outputs cross workgroups inside one launch (k_chain): loads
+// that bypass the CU's L1 and write-through stores (relaxed, agent scope: global_load / global_store ... sc1), so that neither an
+// acquire nor a release fence is needed around the body (chain_engine.hpp).
+template <bool SC1, typename T> __device__ __forceinline__ T dg_ld(const T *p) {
+  if constexpr (SC1) {
+    if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else return __builtin_bit_cast(T, __hip_atomic_load(reinterpret_cast<const long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  } else return *p;
+}
+template <bool SC1, typename T> __device__ __forceinline__ void dg_st(T *p, T v) {
+  if constexpr (SC1) {
+    if constexpr (sizeof(T) == 4) __hip_atomic_store(reinterpret_cast<int *>(p), __builtin_bit_cast(int, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(reinterpret_cast<long long *>(p), __builtin_bit_cast(long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else *p = v;
+}
+
+// The body as a device function (all 512 threads of the workgroup; `smem`: DIAG_LDS elements, `handover_p`: one int of LDS):
+// k_diag below is one call of it per launch, the resident chain kernel of the sweep (potrf.hip, k_chain) calls it once per
+// block row of a group.  blk: the diagonal block (leading dimension ldu), vd: its 128 x 128 inverse-transpose output
+// (leading dimension NB), wo: W_kk output (leading dimension ldwu) or nullptr.  Both roles (factor wave / workers) leave
+// through the end of the function with the same number of barriers executed.
+template <typename T, int DBG = 0, bool SC1 = false>
+__device__ __forceinline__ void diag_body(T *blk, const unsigned ldu, T *__restrict__ vd, T *wo, const unsigned ldwu, T *smem, int *handover_p) {
   using Tr = Traits<T>;
   using acc_t = typename Tr::acc_t;
-  __shared__ __align__(16) T smem[DIAG_LDS];
-  __shared__ int handover;             // highest sub-block row whose diagonal tile is ready in the hand-over buffer
+  int &handover = *handover_p;         // highest sub-block row whose diagonal tile is ready in the hand-over buffer
   T *scr = smem + DIAG_SCR;
-  const int lat = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6) - 1;          // worker id, -1 = factor wave
   const int fm = lane & 15, fk = lane >> 4, lo = fk * SB + fm;
-  T *blk = A + (int64_t)lat * strideA + (int64_t)kblk * NB * lda + (int64_t)kblk * NB;
-  T *vd = Vd + (int64_t)lat * strideV + (int64_t)kblk * NB * NB;
-  T *wo = Wout ? Wout + (int64_t)lat * strideW : nullptr;
-  const unsigned ldu = (unsigned)lda, ldwu = (unsigned)ldw;            // offsets inside the block fit 32 bits
 
   if (w < 0) {
     // =========================== wave 0: the serial chain ===========================
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(NT) void k_diag(T *A, int64_t lda, int64_t strideA,
     {                                  // hand-over buffer for s = 0: [ A(0,0) | I ]
       T v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = blk[(unsigned)(fk + 4 * r) * ldu + (unsigned)fm];
+      for (int r = 0; r < 4; ++r) v[r] = dg_ld<SC1>(blk + ((unsigned)(fk + 4 * r) * ldu + (unsigned)fm));
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         scr[(fk + 4 * r) * DIAG_SLD + fm] = v[r];
@@ -166,12 +179,13 @@ __global__ __launch_bounds__(NT) void k_diag(T *A, int64_t lda, int64_t strideA,
           const int row = fk + 4 * r, col = fm;
           const T uv = ub[row * SB + col], wv = rb_cur[row * SB + col], wt = rb_cur[col * SB + row];
           if (col >= row) blk[(unsigned)(o + row) * ldu + (unsigned)(o + col)] = uv;
-          vd[(o + row) * NB + o + col] = wt;
-          if (wo) wo[(unsigned)(o + row) * ldwu + (unsigned)(o + col)] = wv;
+          dg_st<SC1>(vd + ((o + row) * NB + o + col), wt);
+          if (wo) dg_st<SC1>(wo + ((unsigned)(o + row) * ldwu + (unsigned)(o + col)), wv);
         }
       }
       __syncthreads();
     }
+    __builtin_amdgcn_s_setprio(0);
     return;
   }
 
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(NT) void k_diag(T *A, int64_t lda, int64_t strideA,
       const int u = isU ? tt + jj : 0;                                  // W tiles: any valid address, value unused
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        ld[t][r] = blk[(unsigned)(SB * tt + Tr::acc_row(lane, r)) * ldu + (unsigned)(SB * u + fm)];
+        ld[t][r] = dg_ld<SC1>(blk + ((unsigned)(SB * tt + Tr::acc_row(lane, r)) * ldu + (unsigned)(SB * u + fm)));
     }
 #pragma unroll
     for (int t = 0; t <= NSB; ++t) {
@@ -272,23 +286,42 @@ __global__ __launch_bounds__(NT) void k_diag(T *A, int64_t lda, int64_t strideA,
           blk[(unsigned)(o + Tr::acc_row(lane, r)) * ldu + (unsigned)(SB * uc + fm)] = acc[s][r];
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vd[(SB * uc + fm) * NB + o + Tr::acc_row(lane, r)] = acc[s][r];
+        for (int r = 0; r < 4; ++r) dg_st<SC1>(vd + ((SB * uc + fm) * NB + o + Tr::acc_row(lane, r)), acc[s][r]);
         if (wo) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            wo[(unsigned)(o + Tr::acc_row(lane, r)) * ldwu + (unsigned)(SB * uc + fm)] = acc[s][r];
+            dg_st<SC1>(wo + ((unsigned)(o + Tr::acc_row(lane, r)) * ldwu + (unsigned)(SB * uc + fm)), acc[s][r]);
         }
       }
     }
   }
+  __builtin_amdgcn_s_setprio(0);
+}
+
+template <typename T, int DBG = 0, int NT = DIAG_NT>
+__global__ __launch_bounds__(NT) void k_diag(T *A, int64_t lda, int64_t strideA, int kblk, T *__restrict__ Vd,
+                                             int64_t strideV, T *Wout, int64_t ldw, int64_t strideW) {
+  static_assert(NT == 512, "tile ownership is laid out for 8 waves");
+  __shared__ __align__(16) T smem[DIAG_LDS];
+  __shared__ int handover;
+  const int lat = blockIdx.x;
+  T *blk = A + (int64_t)lat * strideA + (int64_t)kblk * NB * lda + (int64_t)kblk * NB;
+  T *vd = Vd + (int64_t)lat * strideV + (int64_t)kblk * NB * NB;
+  T *wo = Wout ? Wout + (int64_t)lat * strideW : nullptr;
+  diag_body<T, DBG>(blk, (unsigned)lda, vd, wo, (unsigned)ldw, smem, &handover);   // offsets inside the block fit 32 bits
 }
 
 // log det = 2 sum log(U_ii) and the pivot check of a finished sweep, from the diagonal of U (a pivot that
 // was not positive left NaN / inf / <= 0 behind; info = 1 + index of the first one, 0 if none).
 // grid (q), 256 threads; fixed-order reduction.
+// `chain_ctl` (optional): the control words of the resident chain kernel in the sweep's scratch (potrf.hip, k_chain), one
+// set every `ctl_stride` elements: a raised abort word (a bounded spin ran out -- never seen; it would mean a workgroup of the
+// chain was not resident) is reported as info = PLMC_INFO_CHAIN_ABORT instead of a pivot index.
+constexpr int INFO_CHAIN_ABORT = 0x7ffffff0;
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_logdet(const T *__restrict__ A, int64_t n_pad, int64_t lda, int64_t strideA,
-                                                      double *__restrict__ logdet, int *__restrict__ info) {
+                                                      double *__restrict__ logdet, int *__restrict__ info, const T *chain_ctl = nullptr,
+                                                      int64_t ctl_stride = 0) {
   __shared__ double red[NTHREADS];
   __shared__ int redb[NTHREADS];
   const int lat = blockIdx.x, tid = threadIdx.x;
@@ -308,16 +341,26 @@ __global__ __launch_bounds__(NTHREADS) void k_logdet(const T *__restrict__ A, in
     if (tid < o) { red[tid] += red[tid + o]; redb[tid] = redb[tid + o] < redb[tid] ? redb[tid + o] : redb[tid]; }
     __syncthreads();
   }
-  if (tid == 0) { logdet[lat] = red[0]; info[lat] = redb[0] == 0x7fffffff ? 0 : redb[0]; }
+  if (tid == 0) {
+    logdet[lat] = red[0];
+    info[lat] = redb[0] == 0x7fffffff ? 0 : redb[0];
+    if (chain_ctl && reinterpret_cast<const int *>(chain_ctl + (int64_t)lat * ctl_stride)[1] != 0) info[lat] = INFO_CHAIN_ABORT;
+  }
 }
 
 // Zero the tiles of the diagonal-block outputs that k_diag never writes: Vd tiles (a, b) with a > b (blocks
 // kb < nvd) and W_kk tiles (b, a) above the diagonal (16 x 16 tiles of the diagonal blocks kb < nwd of a matrix with
 // leading dimension ldw, one block every wdiag_step elements).  grid (max(nvd, nwd), q).
+// `pad_col` > 0: also zero the control area of the resident chain kernel (potrf.hip, k_chain) -- the first 128 elements of rows 0
+// and 1 of the matrix at Wd behind column pad_col (the pad column of the group scratch).
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_zero_diag_out(T *__restrict__ Vd, int64_t strideV, int nvd, T *Wd, int64_t ldw,
-                                                             int64_t strideW, int64_t wdiag_step, int nwd) {
+                                                             int64_t strideW, int64_t wdiag_step, int nwd, int64_t pad_col = 0) {
   const int kb = blockIdx.x, lat = blockIdx.y;
+  if (Wd && pad_col > 0 && kb == 0) {
+    T *c0 = Wd + (int64_t)lat * strideW + pad_col;
+    if (threadIdx.x < 128) { c0[threadIdx.x] = T(0); c0[ldw + threadIdx.x] = T(0); }
+  }
   T *vd = kb < nvd ? Vd + (int64_t)lat * strideV + (int64_t)kb * NB * NB : nullptr;
   T *wo = (Wd && kb < nwd) ? Wd + (int64_t)lat * strideW + (int64_t)kb * wdiag_step : nullptr;
   for (int e = threadIdx.x; e < NB * NB; e += NTHREADS) {

@@ -26,6 +26,7 @@
 #include "covariance.hpp"
 #include "diag_block.hpp"
 #include "bf3_engine.hpp"
+#include "chain_engine.hpp"
 #include "../../include/plmc.h"
 
 namespace plmc {
@@ -140,6 +141,161 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
   T *C = Cb + ((int64_t)ib * NB + h0) * ldc + col0;
   if (first) tile_writeback<T, WB_STORE_NEG, MT>(acc, C, ldc, smem);   // C = -P^T P (first touch of a W tile)
   else tile_writeback<T, WB_SUB, MT>(acc, C, ldc, smem);               // C -= P^T P
+}
+
+// ---- The chain of one group as ONE resident launch (chain_engine.hpp).  1-D grid of q + NP workgroups:
+//  * workgroup l < q is the CRITICAL workgroup of latent l: it factors / inverts the diagonal blocks (diag_body) and carries the two
+//    products between two of them itself -- the panel tile right of the diagonal block and the update of the next diagonal block --
+//    so the critical path of a block row never crosses to another workgroup;
+//  * the NP others form a POOL that takes every other tile operation of the q triangles and inverse triangles by TICKET: one
+//    atomic counter hands out the positions of one list -- the operations in the order of the launches this replaces (per block
+//    row r: panel tiles P <- V_r^T P of row r, U tiles right of the diagonal and W tiles left of it; then the rank-128 updates
+//    C -= P_i^T P_j of every tile below, W tiles of column r being first touches C = -P^T W_rr), latent fastest.
+// That list is a topological order of the dependency graph and a ticket is only ever held by a resident workgroup, so the
+// lowest unfinished operation can always run: deadlock-free for ANY number of resident pool workgroups, with no assumption on
+// placement or dispatch order.  Dependencies = version counters per tile (`cnt`, per latent: 8 x 8 U tiles, 8 x 8 W tiles): tile
+// U(i,j) is final at version i + 1 (i updates + its panel solve / factorisation), W(i,c) at i - c + 1.  Every tile receives its
+// operations in the order of the launches, each the same K = 128 product: the results are bit-identical to the launch-per-step chain.
+// Counters live in the pad column of each latent's group scratch Wg (row 0: the 128 counters; row 1 of latent 0: finished
+// workgroups, abort word, ticket counter); zero at entry (k_zero_diag_out at the start of the sweep), zeroed again by the last
+// workgroup to finish.
+// dev: -DPLMC_CHAIN_TRACE stamps the 100 MHz wall clock of the critical workgroup's phases into the pad column of its latent's Wg
+// (rows 2..; tools/chain_trace.py)
+#ifdef PLMC_CHAIN_TRACE
+#define PLMC_CH_STAMP()                                                                                                          \
+  do {                                                                                                                           \
+    if (crit && threadIdx.x == 0) {                                                                                              \
+      reinterpret_cast<long long *>(Wg + (int64_t)blockIdx.x * strideW + (int64_t)(2 + tr_n / 32) * LDG + (int64_t)GMAX * NB)[tr_n % 32] = wall_clock64(); \
+      ++tr_n;                                                                                                                    \
+    }                                                                                                                            \
+  } while (0)
+#else
+#define PLMC_CH_STAMP() do { } while (0)
+#endif
+template <typename T>
+__global__ __launch_bounds__(CH_NT, 2) void k_chain(T *A, int64_t lda, int64_t strideA, int g0, int G, T *__restrict__ Vd, int64_t strideV, T *Wg,
+                                                     int64_t strideW, int q) {
+  constexpr int SMEM = tile_smem_elems<T>() > DIAG_LDS ? tile_smem_elems<T>() : DIAG_LDS;
+  __shared__ __align__(16) T smem[SMEM + 8];
+  int *lds_ctl = reinterpret_cast<int *>(smem + SMEM);     // [0] hand-over flag of diag_body, [1] result of a wait / the ticket drawn
+  const bool crit = (int)blockIdx.x < q;
+  int *ctl = reinterpret_cast<int *>(Wg + (int64_t)LDG + (int64_t)GMAX * NB);        // latent 0: [0] finished workgroups, [1] abort, [2] tickets
+  // helper operations per latent: row r has (G - 1) panel tiles and sum_i ((G - i) + (r + 1)) update tiles, two of them (one of
+  // each) the critical workgroup's while a next block row exists
+  auto row_ops = [&](int r) { const int below = G - 1 - r; return (G - 1) + below * (G - r) / 2 + below * (r + 1) - (below > 0 ? 2 : 0); };
+  int nops = 0;
+  for (int r = 0; r < G; ++r) nops += row_ops(r);
+  if (crit) __builtin_amdgcn_s_setprio(3);
+  else __builtin_amdgcn_s_setprio(2);
+  int step = 0;                                             // critical workgroup: position in its own sequence (3 per block row)
+#ifdef PLMC_CHAIN_TRACE
+  int tr_n = 0;
+#endif
+  PLMC_CH_STAMP();
+#pragma unroll 1
+  while (true) {
+    int lat, r, ph, i, t;
+    if (crit) {
+      lat = blockIdx.x;
+      r = step / 3;
+      const int kind = step - 3 * r;
+      ++step;
+      if (r >= G) break;
+      T *Al = A + (int64_t)lat * strideA + (int64_t)g0 * NB * lda + (int64_t)g0 * NB;
+      T *Wl = Wg + (int64_t)lat * strideW;
+      int *cnt = reinterpret_cast<int *>(Wl + (int64_t)GMAX * NB);
+      if (kind == 0) {
+        // ---- D(r): factor + invert the diagonal block.  Its loads bypass the L1, V_r and W(r,r) leave write-through (SC1 body)
+        if (!chain_wait(cnt + r * GMAX + r, r, nullptr, 0, nullptr, 0, ctl + 1, lds_ctl + 1)) return;
+        PLMC_CH_STAMP();
+        diag_body<T, 0, true>(Al + (int64_t)r * NB * lda + (int64_t)r * NB, (unsigned)lda, Vd + (int64_t)lat * strideV + (int64_t)(g0 + r) * NB * NB,
+                              Wl + (int64_t)r * NB * LDG + (int64_t)r * NB, (unsigned)LDG, smem, lds_ctl);
+        PLMC_CH_STAMP();
+        chain_post(cnt + r * GMAX + r, r + 1);
+        PLMC_CH_STAMP();
+        continue;
+      }
+      if (r + 1 >= G) continue;
+      ph = kind - 1;                                        // the panel tile (r, r+1), then the update of the next diagonal block
+      i = ph ? r + 1 : r;
+      t = 0;
+    } else {
+      if (threadIdx.x == 0) lds_ctl[1] = __hip_atomic_fetch_add(ctl + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int tk = lds_ctl[1];
+      __syncthreads();
+      if (tk >= nops * q || tk < 0) break;
+      lat = tk % q;
+      int e = tk / q;
+      r = 0;
+      while (e >= row_ops(r)) { e -= row_ops(r); ++r; }
+      const int skip = r + 1 < G ? 1 : 0;                   // tile 0 of the panel and of update row r + 1 is the critical workgroup's
+      if (e < (G - 1) - skip) { ph = 0; i = r; t = e + skip; }
+      else {
+        e -= (G - 1) - skip;
+        ph = 1;
+        i = r + 1;
+        while (true) {
+          const int n_i = (G - i) + (r + 1) - (i == r + 1 ? 1 : 0);
+          if (e < n_i) break;
+          e -= n_i;
+          ++i;
+        }
+        t = e + (i == r + 1 ? 1 : 0);
+      }
+    }
+    // ---- one tile operation: phase 0 = panel of row r (i == r), phase 1 = rank-128 update of row i > r with the panel row r
+    T *Al = A + (int64_t)lat * strideA + (int64_t)g0 * NB * lda + (int64_t)g0 * NB;     // U(0,0) of the group
+    T *Wl = Wg + (int64_t)lat * strideW;                                                 // W(0,0)
+    int *cnt = reinterpret_cast<int *>(Wl + (int64_t)GMAX * NB);
+    auto U = [&](int a, int b) { return Al + (int64_t)a * NB * lda + (int64_t)b * NB; };
+    auto W = [&](int a, int b) { return Wl + (int64_t)a * NB * LDG + (int64_t)b * NB; };
+    auto cU = [&](int a, int b) { return cnt + a * GMAX + b; };
+    auto cW = [&](int a, int b) { return cnt + GMAX * GMAX + a * GMAX + b; };
+    const int nUt = ph ? G - i : G - 1 - r;
+    const bool isU = t < nUt;
+    const int j = isU ? (ph ? i + t : r + 1 + t) : t - nUt;                         // U column (>= i / > r) or W column (<= r / < r)
+    T *C = isU ? U(i, j) : W(i, j);                                                 // the tile written (phase 0: in place)
+    const int64_t ldc = isU ? lda : (int64_t)LDG;
+    int *c = isU ? cU(i, j) : cW(i, j);
+    const int v = isU ? r : r - j;                                                  // version the earlier rows left the target in
+    const T *Ap = ph ? U(r, i) : Vd + (int64_t)lat * strideV + (int64_t)(g0 + r) * NB * NB;
+    const int64_t lda_ = ph ? lda : (int64_t)NB;
+    const T *Bp = ph ? (isU ? U(r, j) : W(r, j)) : C;
+    // inputs: phase 0: D(r); phase 1: the panel tiles U(r,i) and U(r,j) / W(r,j) (W(r,r) comes out of D(r))
+    const int *pa = ph ? cU(r, i) : cU(r, r);
+    const int *pb = ph ? (isU ? cU(r, j) : (j == r ? cU(r, r) : cW(r, j))) : nullptr;
+    const int vb = isU ? r + 1 : (j == r ? r + 1 : r - j + 1);
+    if (!chain_wait(c, v, pa, r + 1, pb, vb, ctl + 1, lds_ctl + 1)) return;
+    PLMC_CH_STAMP();
+    Acc<T, 2, 4> acc;
+    acc.zero();
+    const int mode = ph == 0 ? WB_STORE : ((!isU && j == r) ? WB_STORE_NEG : WB_SUB);
+    ChainC<T> vc = {};
+    // fp32: the C tile of a read-modify-write is requested right behind the operand loads (32 more registers); fp64 (whose
+    // operand bursts already fill the registers) requests it after the product
+    constexpr bool CPRE = sizeof(T) == 4;
+    auto pre = [&]() { if (CPRE && mode == WB_SUB) chain_cload<T>(vc, C, ldc); };
+    chain_mainloop<T>(acc, Ap, lda_, Bp, ldc, smem, pre);
+    PLMC_CH_STAMP();
+    if (!CPRE && mode == WB_SUB) chain_cload<T>(vc, C, ldc);
+    chain_writeback<T>(acc, C, ldc, smem, mode, vc);
+    PLMC_CH_STAMP();
+    chain_post(c, v + 1);
+    PLMC_CH_STAMP();
+  }
+  // the last workgroup to get here leaves counters and control words zeroed for the next group's launch
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int prev = __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lds_ctl[1] = prev == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (lds_ctl[1]) {
+    for (int l = 0; l < q; ++l)
+      if (threadIdx.x < 2 * GMAX * GMAX) chain_st(reinterpret_cast<int *>(Wg + (int64_t)l * strideW + (int64_t)GMAX * NB) + threadIdx.x, 0);
+    if (threadIdx.x < 3) chain_st(ctl + threadIdx.x, 0);
+  }
 }
 
 // ---- scales of the split engine's operand families (bf3_engine.hpp).  Per latent eight floats in the Vd scratch:
@@ -929,7 +1085,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   ProfScope whole(PK_SWEEP, st, q * (with_inverse == 2 ? 3.0 : (with_inverse ? 2.0 : 1.0)) * npd * npd * npd / 3.0, 0.0);
   // tiles of the diagonal-block outputs that k_diag leaves alone (they are read as parts of full 128 x 128 operands)
   hipLaunchKernelGGL(k_zero_diag_out<T>, dim3(m > GMAX ? m : GMAX, q), dim3(NTHREADS), 0, st, Vd, strideV, m, Wg, (int64_t)LDG,
-                     strideV, (int64_t)NB * LDG + NB, GMAX);
+                     strideV, (int64_t)NB * LDG + NB, GMAX, (int64_t)GMAX * NB);    // (+ the chain kernel's counters in the pad column of Wg)
   if constexpr (bf3)                                      // scales of the operand families (SplitB3: ones), before anything splits
   {
     if (SS::NPL == 2)
@@ -937,7 +1093,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     hipLaunchKernelGGL((k_split_scales<SS>), dim3(q), dim3(64), 0, st, n_pad, eig_lo, scl, sc_lat);
   }
   auto finish = [&]() {
-    hipLaunchKernelGGL(k_logdet<T>, dim3(q), dim3(NTHREADS), 0, st, (const T *)A, n_pad, lda, strideA, logdet, info);
+    hipLaunchKernelGGL(k_logdet<T>, dim3(q), dim3(NTHREADS), 0, st, (const T *)A, n_pad, lda, strideA, logdet, info,
+                       (const T *)(Wg + (int64_t)LDG + (int64_t)GMAX * NB), (int64_t)0);    // (the chain kernel's abort word: latent 0's)
     return launch_status("potrf_impl");
   };
   // Group boundaries.  Large groups divide the read-modify-write traffic of the trailing matrix by G and put
@@ -958,8 +1115,19 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
 
   // ---- the pieces of one group gi (rows g0 .. g1-1; next group g1 .. g2-1; the one after g2 .. g3-1)
   // chain: the group's diagonal triangle + its inverse triangle in Wg
+  // resident form (k_chain): one launch per group, q critical workgroups + a pool for the ~220 other tile operations per latent
+  // and group of 8 (12-16 us each).  The pool is sized to keep up with the critical workgroups' ~40 us per block row without
+  // holding more CUs than that (a chain workgroup does not fit on a CU beside a 228-register bulk workgroup); PLMC_CHAIN_NW
+  // overrides, PLMC_CHAIN=0 brings the launches back.
+  const int chain_pool = kn.chain_nw > 0 ? (kn.chain_nw < 240 ? kn.chain_nw : 240) : (q >= 8 ? 56 : (q >= 4 ? 44 : (q >= 2 ? 36 : 31)));
   auto chain = [&](int gi, hipStream_t s) {
     const int g0 = G0(gi), g1 = G0(gi + 1);
+    if (kn.chain) {
+      const int G = g1 - g0;
+      ProfScope ps(PK_DIAG, s, q * (2.0 / 3.0) * nb3 * G, q * 3.0 * nb * nb * esz * G);
+      hipLaunchKernelGGL((k_chain<T>), dim3(q + (G > 1 ? chain_pool : 0)), dim3(CH_NT), 0, s, A, lda, strideA, g0, G, Vd, strideV, Wg, strideV, q);
+      return;
+    }
     for (int r = g0; r < g1; ++r) {
       diag(r, g0, s);
       panel(r, cm_tri(g0, r + 1, g1 - 1 - r, g0, r - g0), s);

@@ -168,6 +168,7 @@ def factorize_checked(kind, X, ell, oscale, noise, rhs, ws, Xs=None):
     if not settings.check_cholesky.on():
         return 0.0
     info = ws.info.cpu()
+    _check_chain_abort(info)
     if not bool(info.any()):
         return 0.0
     base = settings.cholesky_jitter.value(ws.dtype)
@@ -181,6 +182,15 @@ def factorize_checked(kind, X, ell, oscale, noise, rhs, ws, Xs=None):
             return jit
     raise RuntimeError("Matrix not positive definite after repeatedly adding jitter up to %.1e "
                        "(first failing pivot per latent: %s)" % (jit, info.tolist()))
+
+
+INFO_CHAIN_ABORT = 0x7ffffff0      # csrc/diag_block.hpp: the sweep's resident chain kernel gave up a bounded wait (never a pivot index)
+
+
+def _check_chain_abort(info_host):
+    if bool((info_host == INFO_CHAIN_ABORT).any()):
+        raise RuntimeError("projectedlmc: the resident chain kernel of the blocked sweep timed out waiting for another workgroup "
+                           "(internal error -- not a property of the matrix); PLMC_CHAIN=0 selects the launch-per-step chain")
 
 
 class deferred_pivot_checks:
@@ -225,6 +235,7 @@ class _DeferredInfo:
 
     def failed(self):
         self.event.synchronize()
+        _check_chain_abort(self.host)
         return bool(self.host.any())
 
 

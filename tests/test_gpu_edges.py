@@ -249,6 +249,16 @@ def _schedule_independence_body(eng, n, q, dtype):
         assert ndiff == 0, "run %d: %d elements of the factor buffer differ from the one-stream schedule" % (rep, ndiff)
         assert torch.equal(ld, ld_ref) and torch.equal(info, info_ref)
         del A
+    # (c) the chain of a group as ONE resident launch (k_chain: workgroups handing tiles over through version counters) performs
+    # the tile operations of the three launches per block row it replaces, in the same order per tile: the launch-per-step chain
+    # (PLMC_CHAIN=0) and other pool sizes (PLMC_CHAIN_NW: 1, 5, 200 workgroups beside the q critical ones) give the same bits
+    for knob, val in (("PLMC_CHAIN", "0"), ("PLMC_CHAIN_NW", "1"), ("PLMC_CHAIN_NW", "5"), ("PLMC_CHAIN_NW", "200")):
+        with _hip.knob(knob, val):
+            A, ld, info = factor()
+        ndiff = int((A != ref).sum())
+        assert ndiff == 0, "%s=%s: %d elements of the factor buffer differ" % (knob, val, ndiff)
+        assert torch.equal(ld, ld_ref) and torch.equal(info, info_ref)
+        del A
     del ref, ws
     torch.cuda.empty_cache()
 

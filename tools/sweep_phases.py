@@ -14,7 +14,7 @@ ev = [(nm(r), (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) -
 groups = []
 cur = None
 for name, s, e, q in ev:
-    if name.startswith("k_diag"):
+    if name.startswith("k_diag") or name.startswith("k_chain"):      # (k_chain: the resident chain, one launch per group)
         if cur is None or "vtrans" in cur:
             cur = {"chain": [s, e], "ndiag": 0}
             groups.append(cur)
@@ -33,7 +33,7 @@ def span(d, key, s, e):
     else:
         d[key] = [s, e]
 # bulk kernels: attribute to groups in order of appearance per class
-chainq = next((q for name, s, e, q in ev if name.startswith("k_diag")), None)       # the chain's queue: the head panel runs there
+chainq = next((q for name, s, e, q in ev if name.startswith("k_diag") or name.startswith("k_chain")), None)       # the chain's queue: the head panel runs there
 cls_of = lambda n, q=None: ("gp_head" if n.startswith("k_gpanel_rows<float, 1") or n.startswith("k_gpanel_rows<double, 1") or (n.startswith("k_gpanel_bf3") and q == chainq) else
                     "gp_rest" if n.startswith("k_gpanel_rows") or n.startswith("k_gpanel_bf3") else
                     "U1" if n.startswith("k_update<float, 2") or n.startswith("k_update<double, 2") or (n.startswith("k_update_bf3<") and n.endswith(" 2>")) else
