@@ -23,16 +23,28 @@ constexpr int CH_AUX = 16;                                  // sc1: loads bypass
 // slabs of 16 contraction rows in flight per burst: fp32 all 8 of K = 128 (64 staging registers), fp64 4 (64 registers)
 template <typename T> constexpr int CH_BURST = sizeof(T) == 8 ? 4 : 8;
 
+// Wave -> (wave row wm, wave column wn) of the 128 x 128 tile: waves 0..3 take rows 0..63, waves 4..7 rows 127..64 (wm = 3, 3, 2, 2):
+// waves w and w + 4 share a SIMD, so each SIMD carries a top and a bottom wave row -- what balances the triangular panel
+// products (TRI below), whose wave row wm multiplies only 2 wm + 2 of the 8 slabs.  Every element still sees the same k order.
+__device__ __forceinline__ void chain_wave_pos(int wave, int &wm, int &wn) {
+  wm = wave < 4 ? wave >> 1 : 3 - ((wave - 4) >> 1);
+  wn = wave & 1;
+}
+
 // acc += sum_{k < 128} Ag[k][0..127]^T Bg[k][0..127]   for the whole 128 x 128 tile on 8 waves: wave (wm, wn) = (w >> 1, w & 1)
 // owns rows 32 wm .., columns 64 wn .. (2 x 4 MFMA tiles).  Same LDS layout and the same accumulation order per element as
 // tile_mainloop / tile_mainloop_burst (gemm_core.hpp): bit-identical results.  smem: tile_smem_elems<T>() elements.
 // All 512 threads must call it; ends with a barrier.
+// tri (run-time, workgroup-uniform): A is UPPER triangular with exact zeros below its diagonal (the inverse diagonal block V_r of
+// the panel products): row i of the product only has terms k <= i, so wave row wm skips the slabs beyond 2 wm + 1 -- the skipped
+// terms are exact zeros times finite numbers, the sums are unchanged bit for bit (a non-finite operand already means a failed
+// factorisation, reported through `info`).
 // `pre`: called once, right behind the loads of the first burst -- the place for the C tile's loads of a read-modify-write
 // operation (chain_cload), so that they are in flight during the product instead of being one more round trip behind it.
 struct ChainNoPre { __device__ __forceinline__ void operator()() const {} };
 template <typename T, class PRE = ChainNoPre>
 __device__ __forceinline__ void chain_mainloop(Acc<T, 2, 4> &acc, const T *__restrict__ Ag, int64_t lda, const T *__restrict__ Bg, int64_t ldb, T *smem,
-                                               PRE pre = PRE()) {
+                                               PRE pre = PRE(), const bool tri = false) {
   using Tr = Traits<T>;
   using vec_t = typename Tr::vec_t;
   constexpr int EPV = Tr::EPV, BURST = CH_BURST<T>;
@@ -44,7 +56,9 @@ __device__ __forceinline__ void chain_mainloop(Acc<T, 2, 4> &acc, const T *__res
   asm volatile("" : "+v"(tid));                             // (see chain_writeback)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  int wm, wn;
+  chain_wave_pos(wave, wm, wn);
+  const int nslab = tri ? 2 * wm + 2 : NB / BK;             // slabs this wave multiplies
   T *sA = smem, *sB = smem + SB_OFF;
   const int row0 = tid / CPR, col0 = (tid % CPR) * EPV;
   const char *baseA = reinterpret_cast<const char *>(Ag), *baseB = reinterpret_cast<const char *>(Bg);
@@ -85,17 +99,19 @@ __device__ __forceinline__ void chain_mainloop(Acc<T, 2, 4> &acc, const T *__res
       }
       __syncthreads();                                      // slab s visible; every wave is past the reads of slab s - 1
       const T *pa = pa0 + buf * (BK * LDT), *pb = pb0 + buf * (BK * LDT);
+      if (bt * BURST + s < nslab) {
 #pragma unroll
-      for (int ks = 0; ks < BK / 4; ++ks) {
-        T a[2], b[4];
+        for (int ks = 0; ks < BK / 4; ++ks) {
+          T a[2], b[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) a[t] = pa[ks * LDT + t * 16];
+          for (int t = 0; t < 2; ++t) a[t] = pa[ks * LDT + t * 16];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = pb[ks * LDT + t * 16];
+          for (int t = 0; t < 4; ++t) b[t] = pb[ks * LDT + t * 16];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+          for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) acc.v[mt][nt] = Tr::mfma(a[mt], b[nt], acc.v[mt][nt]);
+            for (int nt = 0; nt < 4; ++nt) acc.v[mt][nt] = Tr::mfma(a[mt], b[nt], acc.v[mt][nt]);
+        }
       }
     }
     __syncthreads();                                        // both stages free (next burst / the caller's epilogue)
@@ -138,7 +154,8 @@ __device__ __forceinline__ void chain_writeback(const Acc<T, 2, 4> &acc, T *Cg, 
   asm volatile("" : "+v"(tid));                             // per-operation index arithmetic stays inside the operation (not hoisted out of the op loop into registers)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  int wm, wn;
+  chain_wave_pos(wave, wm, wn);
   const int row0 = tid / CPR, col0 = (tid % CPR) * EPV;
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(Cg, 0, 0x7fffffff, 0x00020000);
   const unsigned voff = (unsigned)(((int64_t)row0 * ldc + col0) * (int64_t)sizeof(T));
@@ -165,6 +182,70 @@ __device__ __forceinline__ void chain_writeback(const Acc<T, 2, 4> &acc, T *Cg, 
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o), rC, voff + (unsigned)(half * (64 / RSTEP) + h) * rstep, 0, CH_AUX);
     }
   }
+}
+
+// The critical workgroup's fused step between two diagonal blocks: `acc` holds the finished panel tile P = U(r, r+1) (the result of
+// chain_mainloop with V_r).  In two passes of 64 rows P goes through the LDS staging area -- in the main loop's slab layout -- and
+// from there (a) to memory (write-through, for the pool's updates of the rows below) and (b) straight back into the matrix cores
+// as BOTH operands of the next diagonal block's update:  acc2 += P^T P, slab by slab in the order chain_mainloop would take them
+// from memory (bit-identical), without the store -> flag -> load round trip of two separate operations.  smem: 64 x LDT elements.
+template <typename T>
+__device__ __forceinline__ void chain_panel_then_update(const Acc<T, 2, 4> &acc, Acc<T, 2, 4> &acc2, T *Pg, int64_t ldp, T *smem) {
+  using Tr = Traits<T>;
+  using vec_t = typename Tr::vec_t;
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
+  constexpr int EPV = Tr::EPV, CPR = 128 / EPV, NCH = 64 * CPR / CH_NT, RSTEP = CH_NT / CPR;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wm, wn;
+  chain_wave_pos(wave, wm, wn);
+  const int row0 = tid / CPR, col0 = (tid % CPR) * EPV;
+  const int fk = lane >> 4, fm = lane & 15;
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(Pg, 0, 0x7fffffff, 0x00020000);
+  const unsigned voff = (unsigned)(((int64_t)row0 * ldp + col0) * (int64_t)sizeof(T));
+  const unsigned rstep = (unsigned)((int64_t)RSTEP * ldp * (int64_t)sizeof(T));
+  // contraction row kk (0..63 inside a pass) -> LDS row: slab kk / 16, inside it (kk % 16 = 4 ks + fk) -> 4 fk + ks (tile_mainloop)
+  auto lrow = [](int kk) { return (kk & ~15) + ((kk & 3) << 2) + ((kk & 15) >> 2); };
+  const T *pa0 = smem + fk * 4 * LDT + wm * 32 + fm, *pb0 = smem + fk * 4 * LDT + wn * 64 + fm;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();                              // every wave is past the reads of the previous pass
+    if ((wm >> 1) == half) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lr = lrow((wm & 1) * 32 + mt * 16 + Tr::acc_row(lane, r));
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) smem[lr * LDT + wn * 64 + nt * 16 + (lane & 15)] = acc.v[mt][nt][r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {                         // (a) the rows of P to memory
+      const vec_t sv = *reinterpret_cast<const vec_t *>(smem + lrow(row0 + h * RSTEP) * LDT + col0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, sv), rP, voff + (unsigned)(half * (64 / RSTEP) + h) * rstep, 0, CH_AUX);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {                           // (b) four slabs of 16 contraction rows
+      const T *pa = pa0 + s * (BK * LDT), *pb = pb0 + s * (BK * LDT);
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        T a[2], b[4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t] = pa[ks * LDT + t * 16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = pb[ks * LDT + t * 16];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc2.v[mt][nt] = Tr::mfma(a[mt], b[nt], acc2.v[mt][nt]);
+      }
+    }
+  }
+  __syncthreads();                                          // staging area free for the write-back of the update
 }
 
 // ---- version counters (ints in device memory, one per tile; all accesses relaxed, agent scope)

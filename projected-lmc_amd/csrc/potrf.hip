@@ -187,7 +187,7 @@ __global__ __launch_bounds__(CH_NT, 2) void k_chain(T *A, int64_t lda, int64_t s
   for (int r = 0; r < G; ++r) nops += row_ops(r);
   if (crit) __builtin_amdgcn_s_setprio(3);
   else __builtin_amdgcn_s_setprio(2);
-  int step = 0;                                             // critical workgroup: position in its own sequence (3 per block row)
+  int step = 0;                                             // critical workgroup: position in its own sequence (2 per block row)
 #ifdef PLMC_CHAIN_TRACE
   int tr_n = 0;
 #endif
@@ -197,28 +197,51 @@ __global__ __launch_bounds__(CH_NT, 2) void k_chain(T *A, int64_t lda, int64_t s
     int lat, r, ph, i, t;
     if (crit) {
       lat = blockIdx.x;
-      r = step / 3;
-      const int kind = step - 3 * r;
+      r = step >> 1;
+      const int kind = step & 1;
       ++step;
       if (r >= G) break;
       T *Al = A + (int64_t)lat * strideA + (int64_t)g0 * NB * lda + (int64_t)g0 * NB;
       T *Wl = Wg + (int64_t)lat * strideW;
+      T *Vr = Vd + (int64_t)lat * strideV + (int64_t)(g0 + r) * NB * NB;
       int *cnt = reinterpret_cast<int *>(Wl + (int64_t)GMAX * NB);
       if (kind == 0) {
-        // ---- D(r): factor + invert the diagonal block.  Its loads bypass the L1, V_r and W(r,r) leave write-through (SC1 body)
-        if (!chain_wait(cnt + r * GMAX + r, r, nullptr, 0, nullptr, 0, ctl + 1, lds_ctl + 1)) return;
+        // ---- D(r): factor + invert the diagonal block (its last update was this workgroup's own: nothing to wait for beyond the
+        // entry state).  Its loads bypass the L1, V_r and W(r,r) leave write-through (SC1 body)
+        if (r == 0 && !chain_wait(cnt, 0, nullptr, 0, nullptr, 0, ctl + 1, lds_ctl + 1)) return;
         PLMC_CH_STAMP();
-        diag_body<T, 0, true>(Al + (int64_t)r * NB * lda + (int64_t)r * NB, (unsigned)lda, Vd + (int64_t)lat * strideV + (int64_t)(g0 + r) * NB * NB,
-                              Wl + (int64_t)r * NB * LDG + (int64_t)r * NB, (unsigned)LDG, smem, lds_ctl);
+        diag_body<T, 0, true>(Al + (int64_t)r * NB * lda + (int64_t)r * NB, (unsigned)lda, Vr, Wl + (int64_t)r * NB * LDG + (int64_t)r * NB, (unsigned)LDG,
+                              smem, lds_ctl);
         PLMC_CH_STAMP();
         chain_post(cnt + r * GMAX + r, r + 1);
         PLMC_CH_STAMP();
         continue;
       }
       if (r + 1 >= G) continue;
-      ph = kind - 1;                                        // the panel tile (r, r+1), then the update of the next diagonal block
-      i = ph ? r + 1 : r;
-      t = 0;
+      // ---- the two products between D(r) and D(r + 1), fused (chain_panel_then_update): P = V_r^T U(r, r+1), then
+      // U(r+1, r+1) -= P^T P with P taken from LDS.  Inputs from the pool: both tiles at version r
+      T *Pg = Al + (int64_t)r * NB * lda + (int64_t)(r + 1) * NB, *Cg = Al + (int64_t)(r + 1) * NB * lda + (int64_t)(r + 1) * NB;
+      int *cP = cnt + r * GMAX + r + 1, *cC = cnt + (r + 1) * GMAX + r + 1;
+      if (!chain_wait(cP, r, cC, r, nullptr, 0, ctl + 1, lds_ctl + 1)) return;
+      PLMC_CH_STAMP();
+      Acc<T, 2, 4> accp, accu;
+      accp.zero();
+      accu.zero();
+      ChainC<T> vcc = {};
+      constexpr bool CPRE2 = sizeof(T) == 4;
+      auto pre2 = [&]() { if (CPRE2) chain_cload<T>(vcc, Cg, lda); };
+      chain_mainloop<T>(accp, Vr, NB, Pg, lda, smem, pre2, true);
+      PLMC_CH_STAMP();
+      chain_panel_then_update<T>(accp, accu, Pg, lda, smem);
+      PLMC_CH_STAMP();
+      chain_post(cP, r + 1);
+      PLMC_CH_STAMP();
+      if (!CPRE2) chain_cload<T>(vcc, Cg, lda);
+      chain_writeback<T>(accu, Cg, lda, smem, WB_SUB, vcc);
+      PLMC_CH_STAMP();
+      chain_post(cC, r + 1);
+      PLMC_CH_STAMP();
+      continue;
     } else {
       if (threadIdx.x == 0) lds_ctl[1] = __hip_atomic_fetch_add(ctl + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
@@ -276,7 +299,7 @@ __global__ __launch_bounds__(CH_NT, 2) void k_chain(T *A, int64_t lda, int64_t s
     // operand bursts already fill the registers) requests it after the product
     constexpr bool CPRE = sizeof(T) == 4;
     auto pre = [&]() { if (CPRE && mode == WB_SUB) chain_cload<T>(vc, C, ldc); };
-    chain_mainloop<T>(acc, Ap, lda_, Bp, ldc, smem, pre);
+    chain_mainloop<T>(acc, Ap, lda_, Bp, ldc, smem, pre, ph == 0);                // (panel products: V_r is upper triangular)
     PLMC_CH_STAMP();
     if (!CPRE && mode == WB_SUB) chain_cload<T>(vc, C, ldc);
     chain_writeback<T>(acc, C, ldc, smem, mode, vc);
@@ -1119,7 +1142,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // and group of 8 (12-16 us each).  The pool is sized to keep up with the critical workgroups' ~40 us per block row without
   // holding more CUs than that (a chain workgroup does not fit on a CU beside a 228-register bulk workgroup); PLMC_CHAIN_NW
   // overrides, PLMC_CHAIN=0 brings the launches back.
-  const int chain_pool = kn.chain_nw > 0 ? (kn.chain_nw < 240 ? kn.chain_nw : 240) : (q >= 8 ? 56 : (q >= 4 ? 44 : (q >= 2 ? 36 : 31)));
+  const int chain_pool = kn.chain_nw > 0 ? (kn.chain_nw < 240 ? kn.chain_nw : 240) : (q >= 8 ? 80 : (q >= 4 ? 44 : (q >= 2 ? 36 : 31)));
   auto chain = [&](int gi, hipStream_t s) {
     const int g0 = G0(gi), g1 = G0(gi + 1);
     if (kn.chain) {

@@ -15,7 +15,7 @@ tile engine (`plmc_gemm_tn` through `_dense.gemm_tn`; every product is written i
 import torch
 
 from . import _hip
-from ._engine import Workspace, _contig
+from ._engine import Workspace, _contig, _DeferredInfo, _check_chain_abort
 
 _ws = {}
 
@@ -28,6 +28,12 @@ def _workspace(m, q, n, dtype, device, with_inverse):
         ws = Workspace(m, q, n, dtype, device, with_inverse)
         _ws[key] = ws
     return ws
+
+
+def _raise_if_not_pd(check):
+    """Wait for the deferred pivot check of a sweep (a copy of `info` in pinned memory + its event) and raise as the eager check did."""
+    if check.failed():
+        raise RuntimeError("K_ZZ + jitter not positive definite (first failing pivot per latent: %s)" % check.host.tolist())
 
 
 def kernel_vjp(kind, X1, X2, ell, oscale, G):
@@ -73,9 +79,13 @@ class WhitenedInterp(torch.autograd.Function):
         # eig_lo = the jitter: lambda_min(K_ZZ + jitter I) >= jitter (bound for the fp16 split of the bulk fp32 products)
         L.call("plmc_potrf_ex", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, n, ws.strideA, _hip.ptr(ws.Vd),
                _hip.ptr(ws.logdet), _hip.ptr(ws.info), int(need_grad), q, _hip.ptr(jit), st)
-        info = ws.info.cpu()
-        if bool(info.any()):
-            raise RuntimeError("K_ZZ + jitter not positive definite (first failing pivot per latent: %s)" % info.tolist())
+        # the pivot check does not stall the step: `info` goes to pinned host memory behind the sweep and is looked at in
+        # backward() (the whole forward pass -- the ELBO's contractions -- is queued by then; the pattern of
+        # _engine._DeferredInfo); without a backward pass (no gradient needed) it is looked at now
+        check = _DeferredInfo(ws)
+        ctx.pivot_check = check if need_grad else None
+        if not need_grad:
+            _raise_if_not_pd(check)
         A = ws.A[:, :m, ws.n_pad:ws.n_pad + n].clone()
         if need_grad:
             U = torch.triu(ws.A[:, :m, :m])                                     # L^T
@@ -87,6 +97,8 @@ class WhitenedInterp(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, G):
+        if ctx.pivot_check is not None:
+            _raise_if_not_pd(ctx.pivot_check)
         A, U, W, Z, X, ell, osc = ctx.saved_tensors
         osc = osc if ctx.has_os else None
         kind = ctx.kind
@@ -145,9 +157,10 @@ class GaussianKLToKernelPrior(torch.autograd.Function):
         L.call("plmc_write_rhs", dt, _hip.ptr(rhs_t), n + 1, n, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, ws.naug_pad, q, st)
         L.call("plmc_potrf_ex", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, n + 1, ws.strideA, _hip.ptr(ws.Vd),
                _hip.ptr(ws.logdet), _hip.ptr(ws.info), 1, q, _hip.ptr(jit), st)
-        info = ws.info.cpu()
-        if bool(info.any()):
-            raise RuntimeError("K_ZZ + jitter not positive definite (first failing pivot per latent: %s)" % info.tolist())
+        check = _DeferredInfo(ws)                                                      # looked at in backward() (see WhitenedInterp)
+        ctx.pivot_check = check if any(ctx.needs_input_grad[:5]) else None
+        if ctx.pivot_check is None:
+            _raise_if_not_pd(check)
         Zs = ws.A[:, :n, ws.n_pad:ws.n_pad + n + 1]                                  # U^-T [m, Ls]
         sq = (Zs.double() ** 2).sum(-2)                                              # (q, n+1) column norms
         quad, tr = sq[:, 0], sq[:, 1:].sum(-1)
@@ -161,6 +174,8 @@ class GaussianKLToKernelPrior(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.pivot_check is not None:
+            _raise_if_not_pd(ctx.pivot_check)
         W, Zs, Z, ell, osc, dg = ctx.saved_tensors
         osc = osc if ctx.has_os else None
         dt = W.dtype

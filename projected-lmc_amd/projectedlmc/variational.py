@@ -58,10 +58,23 @@ class VariationalStrategy(torch.nn.Module):
         self.register_buffer("variational_params_initialized", torch.tensor(0))
         self.jitter_val = jitter_val
 
+    def _initialized(self):
+        """`variational_params_initialized` (a device buffer, as in gpytorch: part of the state dict) without a device-to-host
+        sync per training step: once it has been seen set it stays set for this module object (it is only ever raised; a
+        load_state_dict that lowers it comes with a fresh look because the buffer's version changes)."""
+        b = self.variational_params_initialized
+        seen = self.__dict__.get("_init_seen")
+        if seen is not None and seen == (b._version, b.data_ptr()):
+            return True
+        done = bool(b.item())
+        if done:
+            self.__dict__["_init_seen"] = (b._version, b.data_ptr())
+        return done
+
     def latent_moments(self, x):
         """(mean_f (q,n), var_f (q,n)) of q(f) at x and KL(q(u) || p(u)) (q,)."""
         model = self.model
-        if not bool(self.variational_params_initialized.item()):
+        if not self._initialized():
             self._variational_distribution.initialize_variational_distribution()
             self.variational_params_initialized.fill_(1)
         kern = model.covar_module
@@ -133,7 +146,7 @@ class UnwhitenedVariationalStrategy(VariationalStrategy):
         jit = self.jitter_val if self.jitter_val is not None else self.PRIOR_JITTER
         vd = self._variational_distribution
         Zs = kern.select(Z)
-        if not bool(self.variational_params_initialized.item()):
+        if not self._initialized():
             with torch.no_grad():
                 Lp = _var_engine.prior_cholesky(kind, Zs, ell, osc, jit)
             vd.initialize_variational_distribution(prior_chol=Lp)

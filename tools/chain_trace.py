@@ -2,7 +2,7 @@
 build with -DPLMC_CHAIN_TRACE:
     make -C projected-lmc_amd/csrc BUILD=build_trace TARGET=$PWD/tools/variants/libplmc_trace.so EXTRA=-DPLMC_CHAIN_TRACE
     PLMC_LIB=tools/variants/libplmc_trace.so python tools/chain_trace.py [q]
-One group (n = 1024), chain alone on the device; stamps are the 100 MHz wall clock: 11 per block row."""
+One group (n = 1024), chain alone on the device; stamps are the 100 MHz wall clock: 9 per block row."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "projected-lmc_amd")]
@@ -24,10 +24,10 @@ NB, GMAX = 128, 8
 LDG = (GMAX + 1) * NB
 m = ws.m
 Wg = ws.Vd[0].reshape(-1)[m * NB * NB:]
-names = ["waitD", "diag", "postD", "waitP", "loopP", "wbP", "postP", "waitU", "loopU", "wbU", "postU"]
+names = ["waitD", "diag", "postD", "waitP", "loopP", "fuse", "postP", "wbU", "postU"]
 rows = []
 st = []
-for k in range(1 + 11 * 8):
+for k in range(1 + 9 * 8):
     off = (2 + k // 32) * LDG + GMAX * NB + 2 * (k % 32)
     st.append(int(Wg[off:off + 2].view(torch.int64)[0]))
 print("info", ws.info.tolist())
