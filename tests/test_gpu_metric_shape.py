@@ -37,10 +37,12 @@ def eng():
 
 
 def _host_threads():
+    """bench.py's workload generator.  (No torch.set_num_threads here: changing the thread count of a process that has already
+    run scikit-learn / OpenMP work -- any earlier test's SVD initialisation -- corrupted later CPU results in the same pytest
+    process on the GPU box and hung on the build container; the oracle runs on torch's default thread pool.)"""
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     import bench
-    torch.set_num_threads(bench.host_cores())
     return bench
 
 
