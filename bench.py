@@ -151,7 +151,6 @@ def host_cores():
 def oracle_latent(X, ell, noise, ytil):
     """fp64 oracle of one latent at full size: (logp, gradient vector over lengthscales, noise and every y entry)."""
     from oracle import cpu_step
-    torch.set_num_threads(host_cores())
     lp, ge, gn, gy = cpu_step.latent_step("matern", X.double(), ell.double(), noise.double(), ytil.double(), nu=2.5)
     return float(lp), torch.cat([ge.reshape(-1), gn.reshape(-1), gy.reshape(-1)])
 
@@ -163,7 +162,6 @@ def cpu_baseline(X, Y, P, n_latents):
     (oracle/cpu_step.py projected_step) -- after one untimed latent evaluation (thread pools, page-in).  iters/sec = 1 / t_step."""
     from oracle import cpu_step
     from oracle import projected as pj
-    torch.set_num_threads(host_cores())
     n = X.shape[0]
     with torch.no_grad():
         cpu_step.latent_step(P["kind"], X, pj.lengthscale(P)[0], pj.projected_noise(P)[0], pj.project_data(P, Y)[0], nu=P["nu"])
@@ -215,6 +213,10 @@ def main():
         raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world == 1:
+        # the CPU legs (cpu_baseline, accuracy oracle) use every host core this process may use; set ONCE, before any CPU work of
+        # the process (changing the thread count after OpenMP work has run is what not to do: tests/test_gpu_metric_shape.py)
+        torch.set_num_threads(host_cores())
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch `python bench.py --gpus N` (it starts the ranks itself) or "

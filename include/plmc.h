@@ -60,7 +60,9 @@ const char *plmc_last_error(void);            /* text of the last error on the c
 int64_t     plmc_vd_blocks_for(int64_t n_pad, int64_t lda, int elem_bytes);
 int64_t     plmc_vd_blocks(int64_t n_pad, int64_t lda);
 /* ... for a plmc_potrf_ex_f32 call with with_inverse | 4 (the sweep KEEPS the 16-bit planes of every group's solved rows
- * instead of rolling over two buffers: plmc_potrs_aug_kept_f32 needs them); 4-byte elements only. */
+ * instead of rolling over two buffers: plmc_potrs_aug_kept_f32 needs them); 4-byte elements only.  Such a sweep always works
+ * in groups of 8 block rows (it ignores the dev knob PLMC_GRP: one kept buffer per 8 block rows is what this size reserves and
+ * what plmc_potrs_aug_kept_f32 walks).  plmc_kinv_grad_vd_f32 accepts either scratch: the sweep records its per-latent stride. */
 int64_t     plmc_vd_blocks_keep(int64_t n_pad, int64_t lda);
 /* Bytes of the `partials` scratch plmc_kinv_grad_* needs for (n_pad, q): per-tile partial sums, and for 4-byte elements the
  * bf16 planes of W (6 q n_pad^2 bytes).  plmc_grad_scratch_bytes = the 4-byte size. */
@@ -108,7 +110,10 @@ int plmc_assemble_cross_f64(int kind, const double *X, int n, const double *Xs, 
  * Blocked right-looking Cholesky of the augmented buffer, Khat = U^T U, in place.
  * Replaces torch.linalg.cholesky_ex + the forward triangular solve behind
  * `latent_output.log_prob(proj_target)` (:1201) / ExactMarginalLogLikelihood (experiments.py:233).
- *   logdet[latent] = log det Khat   (double), info[latent] = 0 or 1 + index of first non-PD pivot.
+ *   logdet[latent] = log det Khat   (double), info[latent] = 0 or 1 + index of first non-PD pivot
+ *   (PLMC_INFO_CHAIN_ABORT: the resident chain kernel of the sweep gave up a bounded wait for another workgroup -- an internal
+ *   error, never a property of the matrix; the results are then undefined.  Never observed; PLMC_CHAIN=0 selects the
+ *   launch-per-step chain).
  * naug = number of live augmented columns (0 allowed).
  * with_inverse != 0: also produce W = U^-T in columns [n_pad + naug_pad, n_pad + naug_pad + n_pad)
  * (the identity rides along as further right-hand sides) -- the first half of the Khat^-1 that
@@ -119,6 +124,7 @@ int plmc_assemble_cross_f64(int kind, const double *X, int n, const double *Xs, 
  * strictly LOWER triangle of the square part at block (jb, ib) -- never read otherwise -- and the diagonal tiles in the
  * last n_pad/NB blocks of Vd.  plmc_grad_tiles_* then turns it into the MLL gradient in one HBM-bound pass.
  */
+#define PLMC_INFO_CHAIN_ABORT 0x7ffffff0
 int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd,
                    double *logdet, int *info, int with_inverse, int q, void *stream);
 int plmc_potrf_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, double *Vd,
@@ -197,6 +203,23 @@ int plmc_gemm_tn_f32(int mode, int M, int N, int K, const float *A, int64_t lda,
                      int64_t ldb, int64_t strideB, float *C, int64_t ldc, int64_t strideC, int batch, void *stream);
 int plmc_gemm_tn_f64(int mode, int M, int N, int K, const double *A, int64_t lda, int64_t strideA, const double *B,
                      int64_t ldb, int64_t strideB, double *C, int64_t ldc, int64_t strideC, int batch, void *stream);
+/* The same for operands with TRIANGULAR structure (the factors W = L^-1, L^T = U, Ls and the triangular adjoints of the
+ * Cholesky adjoint): `tri` = OR of the bits below; a tile then only walks the contraction range in which both operands have
+ * entries -- the skipped terms are exact zeros, the result is the same number at a half to a sixth of the flops.  Structure is
+ * declared per 128-block (entries inside a diagonal block may be anything).
+ *   PLMC_TRI_A_LOWER  A[k][i] = 0 for k < 128 (i / 128)        PLMC_TRI_B_LOWER  B[k][j] = 0 for k < 128 (j / 128)
+ *   PLMC_TRI_A_UPPER  A[k][i] = 0 for k >= 128 (i / 128 + 1)
+ *   PLMC_TRI_C_LOWER  only tiles with i / 128 >= j / 128 are computed; the others are left untouched, or, with PLMC_TRI_C_ZERO
+ *                     as well (mode 0 only), written as zeros. */
+#define PLMC_TRI_A_LOWER 1
+#define PLMC_TRI_B_LOWER 2
+#define PLMC_TRI_A_UPPER 4
+#define PLMC_TRI_C_LOWER 8
+#define PLMC_TRI_C_ZERO 16
+int plmc_gemm_tn_tri_f32(int mode, int tri, int M, int N, int K, const float *A, int64_t lda, int64_t strideA, const float *B,
+                         int64_t ldb, int64_t strideB, float *C, int64_t ldc, int64_t strideC, int batch, void *stream);
+int plmc_gemm_tn_tri_f64(int mode, int tri, int M, int N, int K, const double *A, int64_t lda, int64_t strideA, const double *B,
+                         int64_t ldb, int64_t strideB, double *C, int64_t ldc, int64_t strideC, int batch, void *stream);
 
 /*
  * Eval-mode posterior, the reductions behind the augmented sweep (ProjectedGPModel.__call__, projected_lmc.py:1133-1155;
@@ -378,7 +401,7 @@ int plmc_qr_small_f64(const double *A, int m, int n, int64_t lda, double *Q, int
  * device must not overlap (they would race on this bookkeeping); different devices are independent.  The Python layer
  * calls from one thread per process.
  * Dev knobs are environment variables read once per process (PLMC_HALF_TILES, PLMC_GRP, PLMC_KINV_ORDER,
- * PLMC_SERIAL, PLMC_BULK_LDS); plmc_dev_reload_knobs() re-reads them (tests and bench.py change one and reload).  They change
+ * PLMC_SERIAL, PLMC_BULK_LDS, PLMC_CHAIN, PLMC_CHAIN_NW, PLMC_CHAIN_EDGE); plmc_dev_reload_knobs() re-reads them (tests and bench.py change one and reload).  They change
  * schedules; PLMC_GRP also changes the depth of the updates and with it the rounding.  PLMC_SPLIT (0, 2, 3) selects the
  * arithmetic of the bulk fp32 products (see plmc_potrf_ex_f32).  Buffer sizes do not depend on any knob.
  * plmc_prof_mfma_rate: dense MFMA rate (TFLOP/s) of the current device measured with a bare instruction stream

@@ -44,6 +44,7 @@ static void load_knobs() {
   g_knobs.bulk_streams = getenv("PLMC_BULK_STREAMS") ? atoi(getenv("PLMC_BULK_STREAMS")) : 2;
   g_knobs.chain = getenv("PLMC_CHAIN") ? atoi(getenv("PLMC_CHAIN")) : 1;
   g_knobs.chain_nw = getenv("PLMC_CHAIN_NW") ? atoi(getenv("PLMC_CHAIN_NW")) : 0;
+  g_knobs.chain_edge = getenv("PLMC_CHAIN_EDGE") ? atoi(getenv("PLMC_CHAIN_EDGE")) : 0;
   g_knobs_loaded = true;
 }
 const Knobs &knobs() {

@@ -56,7 +56,8 @@ struct Knobs {
                        // products (SplitH2) where the caller gives eigenvalue bounds (plmc_*_ex_f32), SplitB3 otherwise
   int bulk_streams;    // PLMC_BULK_STREAMS: 2 = group panel + head rows on their own helper stream beside the tail, 1 = in front of the tail on the caller's stream
   int chain;           // PLMC_CHAIN: 1 (default) = the chain of a group as one resident launch (k_chain), 0 = three launches per block row
-  int chain_nw;        // PLMC_CHAIN_NW: workgroups per latent of the resident chain (0 = by the number of latents)
+  int chain_edge;      // PLMC_CHAIN_EDGE: pool size for the first and the last two groups of a sweep (<= 0: as the others)
+  int chain_nw;        // PLMC_CHAIN_NW: pool workgroups of the resident chain beside the q critical ones (0 = by the number of latents)
   int kinv_order;      // PLMC_KINV_ORDER: tile order of the gradient kernel (0 XCD-dealt, 1 grid, 4 longest first, 5 = 4 + general epilogue)
 };
 const Knobs &knobs();

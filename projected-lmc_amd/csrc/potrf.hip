@@ -1148,7 +1148,12 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     if (kn.chain) {
       const int G = g1 - g0;
       ProfScope ps(PK_DIAG, s, q * (2.0 / 3.0) * nb3 * G, q * 3.0 * nb * nb * esz * G);
-      hipLaunchKernelGGL((k_chain<T>), dim3(q + (G > 1 ? chain_pool : 0)), dim3(CH_NT), 0, s, A, lda, strideA, g0, G, Vd, strideV, Wg, strideV, q);
+      // (dev knob PLMC_CHAIN_EDGE: another pool size for the first group -- the device to itself -- and the last two -- the drain,
+      // where the chain is the critical path.  Measured at q = 8 / 4 with 144 and 200: 18.26-18.43 / 9.93-10.0 ms/step against
+      // 18.22 / 9.82 with one size for all groups: the extra workgroups mostly wait on the per-latent dependency fronts.)
+      const bool edge = gi == 0 || gi + 2 >= ng;
+      const int pool = (edge && kn.chain_edge > 0) ? kn.chain_edge : chain_pool;
+      hipLaunchKernelGGL((k_chain<T>), dim3(q + (G > 1 ? pool : 0)), dim3(CH_NT), 0, s, A, lda, strideA, g0, G, Vd, strideV, Wg, strideV, q);
       return;
     }
     for (int r = g0; r < g1; ++r) {

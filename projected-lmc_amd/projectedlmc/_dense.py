@@ -94,9 +94,14 @@ def _padded(t, rows, cols):
     return out
 
 
-def gemm_tn(A_km, B_kn):
+TRI_A_LOWER, TRI_B_LOWER, TRI_A_UPPER, TRI_C_LOWER, TRI_C_ZERO = 1, 2, 4, 8, 16      # include/plmc.h PLMC_TRI_*
+
+
+def gemm_tn(A_km, B_kn, tri=0):
     """C = A^T B for batches of K-major operands A (q,K,M), B (q,K,N) -> (q,M,N) on the library's tile engine
     (plmc_gemm_tn): operands are zero-padded to block multiples (a transposed view is made contiguous by the same copy).
+    tri: PLMC_TRI_* bits declaring triangular operands / a lower-triangular result (plmc_gemm_tn_tri: only the contraction
+    range with entries is walked; with TRI_C_LOWER alone the tiles above the block diagonal hold garbage -- take torch.tril).
     No autograd: used inside hand-written backward passes (`_var_engine`)."""
     _hip.require_device(A_km, B_kn)
     L = _hip.lib()
@@ -108,6 +113,10 @@ def gemm_tn(A_km, B_kn):
     A = _padded(A_km.detach(), Kp, Mp)
     B = _padded(B_kn.detach().to(dt), Kp, Np)
     C = torch.empty(q, Mp, Np, dtype=dt, device=dev)
-    L.call("plmc_gemm_tn", dt, 0, Mp, Np, Kp, _hip.ptr(A), Mp, Kp * Mp, _hip.ptr(B), Np, Kp * Np, _hip.ptr(C), Np, Mp * Np, q,
-           _hip.stream_ptr(dev))
+    if tri:
+        L.call("plmc_gemm_tn_tri", dt, 0, int(tri), Mp, Np, Kp, _hip.ptr(A), Mp, Kp * Mp, _hip.ptr(B), Np, Kp * Np, _hip.ptr(C), Np, Mp * Np, q,
+               _hip.stream_ptr(dev))
+    else:
+        L.call("plmc_gemm_tn", dt, 0, Mp, Np, Kp, _hip.ptr(A), Mp, Kp * Mp, _hip.ptr(B), Np, Kp * Np, _hip.ptr(C), Np, Mp * Np, q,
+               _hip.stream_ptr(dev))
     return C[:, :M, :N]

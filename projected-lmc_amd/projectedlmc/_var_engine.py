@@ -103,13 +103,15 @@ class WhitenedInterp(torch.autograd.Function):
         osc = osc if ctx.has_os else None
         kind = ctx.kind
         G = G.contiguous()
-        from ._dense import gemm_tn
+        from ._dense import gemm_tn, TRI_A_LOWER as AL, TRI_B_LOWER as BL, TRI_A_UPPER as AU, TRI_C_LOWER as CL, TRI_C_ZERO as CZ
         mT = lambda t: t.transpose(-1, -2)
-        Cbar = gemm_tn(W, G)                                                    # L^-T G = W^T G  (q,m,n)
-        Lbar = -torch.tril(gemm_tn(mT(Cbar), mT(A)))                            # -tril(Cbar A^T) (q,m,m)
-        P = torch.tril(gemm_tn(mT(U), Lbar))                                    # Phi(L^T Lbar),  L^T = U
+        # every factor here is triangular (W = L^-1 and the adjoints lower, U = L^T upper): the products only walk the contraction
+        # range with entries (plmc_gemm_tn_tri) -- 768 -> ~280 GFLOP at BASELINE config 4 (m = 2000, n = 3000, q = 8)
+        Cbar = gemm_tn(W, G, AL)                                                # L^-T G = W^T G  (q,m,n)
+        Lbar = -torch.tril(gemm_tn(mT(Cbar), mT(A), CL))                        # -tril(Cbar A^T) (q,m,m)
+        P = torch.tril(gemm_tn(mT(U), Lbar, AL | BL | CL))                      # Phi(L^T Lbar),  L^T = U
         P = P - 0.5 * torch.diag_embed(torch.diagonal(P, dim1=-2, dim2=-1))
-        Kbar = gemm_tn(W, gemm_tn(mT(P), W))                                    # W^T (P W)
+        Kbar = gemm_tn(W, gemm_tn(mT(P), W, AU | BL | CL | CZ), AL | BL)        # W^T (P W)
         Kbar = 0.5 * (Kbar + Kbar.transpose(-1, -2))
         # pull the kernel-matrix adjoints back to (Z, ell, oscale); Z enters K_ZZ through both arguments
         gZ1, gE1, gO1 = kernel_vjp(kind, Z, Z, ell, osc, Kbar)
@@ -123,6 +125,33 @@ class WhitenedInterp(torch.autograd.Function):
 
 def whitened_interp(kind, Z, X, ell, oscale, jitter):
     return WhitenedInterp.apply(Z, X, ell, oscale, kind, jitter)
+
+
+class LowerTMatmul(torch.autograd.Function):
+    """Ls^T A for a batch of LOWER-triangular Ls (q,m,m) and A (q,m,n) -- the S-dependent part of the whitened strategy's
+    predictive covariance, Bm = Ls^T A (gpytorch VariationalStrategy [gpytorch-knowledge]; reached from projected_lmc.py:672-683) --
+    with its adjoints, on the library's tile engine with the triangular contraction ranges (plmc_gemm_tn_tri): half the
+    flops of the three dense m x m x n products torch.bmm and its autograd would run.  `Ls` must be lower triangular (the caller
+    passes chol_variational_covar.tril()); the gradient returned for it is the lower triangle."""
+
+    @staticmethod
+    def forward(ctx, Ls, A):
+        from ._dense import gemm_tn, TRI_A_LOWER
+        ctx.save_for_backward(Ls, A)
+        return gemm_tn(Ls, A, TRI_A_LOWER)
+
+    @staticmethod
+    def backward(ctx, G):
+        from ._dense import gemm_tn, TRI_A_UPPER, TRI_C_LOWER
+        Ls, A = ctx.saved_tensors
+        mT = lambda t: t.transpose(-1, -2)
+        gA = gemm_tn(mT(Ls), G, TRI_A_UPPER) if ctx.needs_input_grad[1] else None        # Ls G
+        gLs = torch.tril(gemm_tn(mT(A), mT(G), TRI_C_LOWER)) if ctx.needs_input_grad[0] else None   # tril(A G^T)
+        return gLs, gA
+
+
+def lower_t_matmul(Ls, A):
+    return LowerTMatmul.apply(Ls, A)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -179,11 +208,11 @@ class GaussianKLToKernelPrior(torch.autograd.Function):
         W, Zs, Z, ell, osc, dg = ctx.saved_tensors
         osc = osc if ctx.has_os else None
         dt = W.dtype
-        from ._dense import gemm_tn
-        Af = gemm_tn(W, Zs)                                                          # Khat^-1 [m, Ls] = W^T Zs (q, n, n+1)
+        from ._dense import gemm_tn, TRI_A_LOWER, TRI_B_LOWER
+        Af = gemm_tn(W, Zs, TRI_A_LOWER)                                             # Khat^-1 [m, Ls] = W^T Zs (q, n, n+1)
         g_m = Af[..., 0]
         g_Ls = torch.tril(Af[..., 1:]) - torch.diag_embed((1.0 / dg).to(dt))
-        Kinv = gemm_tn(W, W)
+        Kinv = gemm_tn(W, W, TRI_A_LOWER | TRI_B_LOWER)
         Gk = 0.5 * (Kinv - gemm_tn(Af.transpose(-1, -2), Af.transpose(-1, -2))) * g.to(dt)[:, None, None]
         gZ, gE, gO = kernel_vjp(ctx.kind, Z, Z, ell, osc, Gk)
         gl = g.to(dt)
@@ -237,10 +266,10 @@ def unwhitened_predictive(kind, Z, X, ell, oscale, mvar, Ls, jitter):
     if bool(ws.info.cpu().any()):
         raise RuntimeError("K_ZZ + jitter not positive definite")
     C = ws.A[:, :n, ws.n_pad:ws.n_pad + ns]                                          # U^-T K_ZX
-    from ._dense import gemm_tn
-    B = gemm_tn(torch.tril(ws.W[:, :n, :n]), C)                                      # Khat^-1 K_ZX = W^T C
+    from ._dense import gemm_tn, TRI_A_LOWER
+    B = gemm_tn(torch.tril(ws.W[:, :n, :n]), C, TRI_A_LOWER)                         # Khat^-1 K_ZX = W^T C
     mean = (B.transpose(-1, -2) @ mvar.to(dt).unsqueeze(-1)).squeeze(-1)
     os_ = torch.ones(q, dtype=dt, device=dev) if osc is None else osc
-    LB = gemm_tn(torch.tril(Ls.to(dt)), B)                                            # Ls^T B
+    LB = gemm_tn(torch.tril(Ls.to(dt)), B, TRI_A_LOWER)                               # Ls^T B
     var = os_[:, None] - (C * C).sum(-2) + (LB * LB).sum(-2)
     return mean, var

@@ -87,7 +87,7 @@ class VariationalStrategy(torch.nn.Module):
         mvar = vd.variational_mean.to(dt)
         Ls = vd.chol_variational_covar.to(dt).tril()
         mean_f = (A.transpose(-1, -2) @ mvar.unsqueeze(-1)).squeeze(-1)
-        Bm = Ls.transpose(-1, -2) @ A
+        Bm = _var_engine.lower_t_matmul(Ls, A)                                    # Ls^T A, triangular contraction ranges
         q = ell.shape[0]
         os_ = torch.ones(q, dtype=dt, device=ell.device) if osc is None else osc
         var_f = os_[:, None] + jit - (A * A).sum(-2) + (Bm * Bm).sum(-2)

@@ -212,3 +212,40 @@ def test_unwhitened_eval_predictions_fp64(plmc):
         dist = model(Xs.to(DEV))
     assert torch.allclose(dist.mean.cpu(), mu_ref, rtol=1e-8, atol=1e-10)
     assert torch.allclose(dist.variance.cpu(), var_ref, rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-5)])
+def test_triangular_gemm_ranges_give_the_dense_product(dtype, tol):
+    """plmc_gemm_tn_tri (the products of the Cholesky adjoint behind VariationalMultitaskGPModel, projected_lmc.py:672-683): with
+    triangular operands declared, a tile only walks the contraction range that has entries -- the result must be the dense
+    product.  Sizes that are not block multiples (m = 300, n = 200: padded by the host), every combination the adjoint uses."""
+    from projectedlmc._dense import gemm_tn, TRI_A_LOWER as AL, TRI_B_LOWER as BL, TRI_A_UPPER as AU, TRI_C_LOWER as CL, TRI_C_ZERO as CZ
+    q, m, n = 2, 300, 200
+    g = torch.Generator().manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64).to(DEV, dtype)
+    Lo, Lo2, Up, F = torch.tril(rnd(q, m, m)), torch.tril(rnd(q, m, m)), torch.triu(rnd(q, m, m)), rnd(q, m, n)
+    mT = lambda t: t.transpose(-1, -2)
+    ref = lambda A, B: mT(A).double() @ B.double()
+    def close(got, want):
+        assert (got.double() - want).abs().max() < tol * max(1.0, float(want.abs().max())), float((got.double() - want).abs().max())
+    close(gemm_tn(Lo, F, AL), ref(Lo, F))                                              # W^T G
+    close(torch.tril(gemm_tn(mT(F), mT(F[:, :, :].contiguous()), CL)), torch.tril(ref(mT(F), mT(F))))   # tril(C A^T)
+    close(torch.tril(gemm_tn(mT(Up), Lo, AL | BL | CL)), torch.tril(ref(mT(Up), Lo)))  # tril(U Lbar): U^T stored K-major is lower
+    PW = gemm_tn(mT(Lo), Lo2, AU | BL | CL | CZ)                                       # P W (lower times lower), zeros above
+    close(PW, ref(mT(Lo), Lo2))
+    close(gemm_tn(Lo2, PW, AL | BL), ref(Lo2, ref(mT(Lo), Lo2).to(dtype)))             # W^T (P W)
+    close(gemm_tn(mT(Lo), F, AU), ref(mT(Lo), F))                                      # Ls G
+
+
+def test_lower_t_matmul_matches_torch_autograd():
+    from projectedlmc import _var_engine
+    q, m, n = 2, 260, 150
+    g = torch.Generator().manual_seed(4)
+    Ls0 = torch.tril(torch.randn(q, m, m, generator=g, dtype=torch.float64)).to(DEV)
+    A0 = torch.randn(q, m, n, generator=g, dtype=torch.float64).to(DEV)
+    Gout = torch.randn(q, m, n, generator=g, dtype=torch.float64).to(DEV)
+    Ls1, A1 = Ls0.clone().requires_grad_(), A0.clone().requires_grad_()
+    (_var_engine.lower_t_matmul(Ls1.tril(), A1) * Gout).sum().backward()
+    Ls2, A2 = Ls0.clone().requires_grad_(), A0.clone().requires_grad_()
+    ((Ls2.tril().transpose(-1, -2) @ A2) * Gout).sum().backward()
+    assert torch.allclose(Ls1.grad, Ls2.grad, rtol=1e-10, atol=1e-10) and torch.allclose(A1.grad, A2.grad, rtol=1e-10, atol=1e-10)
