@@ -446,10 +446,12 @@ class PosteriorCache:
 
     def __init__(self):
         self.key, self.ws = None, None
+        self.seen = None                 # state key of the last uncached call (the cache is built on the SECOND call with one key)
         self.hits = self.misses = 0
 
     def drop(self):
         self.key, self.ws = None, None
+        self.seen = None
 
 
 def model_state_key(module, *tensors):
@@ -465,7 +467,12 @@ def exact_posterior(kind, X, ell, oscale, noise, y, Xs, full_cov=False, cache=No
     with v = U^-T k*, z = U^-T y:  mean = v^T z,  cov = K** - v^T v.
     (ExactGPModel.__call__ in eval mode -> gpytorch DefaultPredictionStrategy; reached from
     projected_lmc.py:1134.)  Returns (mean (q,ns), var (q,ns) | cov (q,ns,ns)).
-    cache / key: a PosteriorCache owned by the calling model and its state key -- see PosteriorCache."""
+    cache / key: a PosteriorCache owned by the calling model and its state key -- see PosteriorCache.  The cache is built
+    LAZILY (settings.prediction_cache "lazy", the default): the first call with a given key runs the plain augmented sweep
+    (n^3 / 3 flops, a workspace from the shared pool) and only remembers the key; the second call with the same key pays for the
+    sweep with the inverse factor and the kept planes (2 n^3 / 3, 13 GB at n = 8192, q = 8; ~50 GB per latent at n = 44 484) that
+    every later call then reuses -- a one-shot prediction neither slows down nor holds that memory.  "eager" builds it
+    on the first call, "off" never."""
     _hip.require_device(X, ell, noise, y, Xs)
     L = _hip.lib()
     dt, dev = y.dtype, y.device
@@ -474,13 +481,23 @@ def exact_posterior(kind, X, ell, oscale, noise, y, Xs, full_cov=False, cache=No
     Xc, Xsc, ellc, osc, nzc = (_contig(t, dt) for t in (X, Xs, ell, oscale, noise))
     yc = _contig(y).reshape(q, 1, n)
     st = _hip.stream_ptr(dev)
-    if cache is None:
-        ws = get_workspace(n, q, 1 + ns, dt, dev, False)
-        factorize_checked(kind, Xc, ellc, osc, nzc, yc, ws, Xs=Xsc)
-    else:
+    mode = settings.prediction_cache.value() if cache is not None else "off"
+    hit = False
+    if cache is not None and mode != "off":
         ws = cache.ws
         hit = (ws is not None and cache.key == key and key is not None and ws.dtype == dt and ws.device == dev and ws.n == n and ws.q == q
                and ws.naug >= 1 + ns)
+    # build: eager mode; lazy mode on the second call with one key; or the cached state is the same and only its capacity is short
+    same_state = cache is not None and cache.ws is not None and key is not None and cache.key == key
+    build = cache is not None and mode != "off" and not hit and (mode == "eager" or same_state or (key is not None and cache.seen == key))
+    if not hit and not build:
+        if cache is not None and mode != "off":
+            cache.drop()                                   # (a stale factorisation of another state goes now, not at the next build)
+            cache.seen = key
+            cache.misses += 1
+        ws = get_workspace(n, q, 1 + ns, dt, dev, False)
+        factorize_checked(kind, Xc, ellc, osc, nzc, yc, ws, Xs=Xsc)
+    else:
         if hit:
             # new right-hand sides into the factorised buffer: y (column 0 shares its tile with the first test points, so it
             # is rewritten raw as well), K*^T behind it; then the forward substitution of those columns only

@@ -192,6 +192,12 @@ class ExactGP(torch.nn.Module):
         if c is not None:
             c.drop()
 
+    def clear_prediction_cache(self):
+        """Release the factorisation an eval-mode model keeps between prediction calls.  The cache is keyed on the identity and
+        version counter of every parameter, buffer and the training data: an optimiser step, load_state_dict, train() or
+        set_train_data drop it by themselves; an edit through `.data` (no version bump) does not -- call this after one."""
+        self._drop_prediction_cache()
+
     def train(self, mode=True):
         if mode:
             self._drop_prediction_cache()             # parameters are about to change: release the cached factor buffer

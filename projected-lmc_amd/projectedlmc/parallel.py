@@ -27,38 +27,56 @@ def shard_of(rank=None, world=None):
     return (rank, world)
 
 
-_direct = {"tried": False, "on": False}
+_direct = {"tried": False, "on": False, "device": None}
 
 
 def _direct_rccl():
     """PLMC_COMM=rccl: the all-reduces go through the library's own RCCL communicator (plmc_comm_*, include/plmc.h) instead of
-    torch.distributed, which is then used once, to carry the 128-byte unique id from rank 0 to the others.  Default: off."""
+    torch.distributed, which is then used for the bootstrap only: the 128-byte unique id travels from rank 0 to the others
+    together with a STATUS byte, and a second all-reduce collects every rank's `plmc_comm_init` result -- either every rank ends
+    on the direct path or none does (a rank that failed alone would otherwise fall back to dist.all_reduce while the others wait
+    in ncclAllReduce).  Decided once per process.  Default: off."""
     if _direct["tried"]:
         return _direct["on"]
-    _direct["tried"] = True
     if os.environ.get("PLMC_COMM", "") != "rccl" or not is_distributed() or not torch.cuda.is_available():
+        _direct["tried"] = True
         return False
     from . import _hip
     L = _hip.lib().cdll
     dev = torch.device("cuda", torch.cuda.current_device())
-    uid = torch.zeros(128, dtype=torch.uint8)
+    on_dev = dist.get_backend() == "nccl"
+    msg = torch.zeros(129, dtype=torch.uint8)                 # [status | unique id]
     if dist.get_rank() == 0:
         buf = (ctypes.c_char * 128)()
-        if L.plmc_comm_unique_id(buf) != 0:
-            raise RuntimeError("plmc_comm_unique_id failed: %s" % L.plmc_last_error().decode())
-        uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-    uid = uid.to(dev) if dist.get_backend() == "nccl" else uid
-    dist.broadcast(uid, src=0)
-    raw = bytes(uid.cpu().numpy().tobytes())
-    if L.plmc_comm_init(ctypes.c_char_p(raw), dist.get_rank(), dist.get_world_size()) != 0:
-        raise RuntimeError("plmc_comm_init failed: %s" % L.plmc_last_error().decode())
-    _direct["on"] = True
+        if L.plmc_comm_unique_id(buf) == 0:
+            msg[0] = 1
+            msg[1:] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+    msg = msg.to(dev) if on_dev else msg
+    dist.broadcast(msg, src=0)                                 # (every rank takes part, whatever rank 0's call returned)
+    msg = msg.cpu()
+    ok = 0
+    if int(msg[0]) == 1:
+        raw = bytes(msg[1:].numpy().tobytes())
+        ok = int(L.plmc_comm_init(ctypes.c_char_p(raw), dist.get_rank(), dist.get_world_size()) == 0)
+    agree = torch.tensor([ok], dtype=torch.int32)
+    agree = agree.to(dev) if on_dev else agree
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+    _direct["tried"] = True
+    if int(agree.cpu()[0]) != 1:
+        if ok:
+            L.plmc_comm_destroy()
+        import warnings
+        warnings.warn("PLMC_COMM=rccl: the direct RCCL communicator could not be set up on every rank (%s); using torch.distributed"
+                      % L.plmc_last_error().decode(), RuntimeWarning)
+        return False
+    _direct["on"], _direct["device"] = True, dev
     return True
 
 
 def all_reduce_sum(t):
     if is_distributed():
-        if t.is_cuda and t.dtype in (torch.float32, torch.float64) and t.is_contiguous() and _direct_rccl():
+        if t.is_cuda and t.dtype in (torch.float32, torch.float64) and t.is_contiguous() and _direct_rccl() and t.device == _direct["device"]:
+            # (the communicator is bound to the device that was current at its creation: other tensors go through torch.distributed)
             from . import _hip
             _hip.lib().call("plmc_comm_allreduce_sum", t.dtype, _hip.ptr(t), t.numel(), _hip.stream_ptr(t.device))
         else:

@@ -53,3 +53,20 @@ class check_cholesky(_Value):
     @classmethod
     def on(cls):
         return cls._stack[-1]
+
+
+class prediction_cache(_Value):
+    """prediction_cache("lazy" | "eager" | "off"): when an eval-mode model builds the factorisation it keeps between prediction
+    calls (_engine.PosteriorCache; gpytorch's prediction strategy keeps its own from the first call).  "lazy" (default): on the
+    second call with unchanged parameters and data -- a single prediction costs and holds no more than it did without a cache;
+    "eager": on the first call; "off": never."""
+    _stack = ["lazy"]
+
+    def __init__(self, value):
+        if value not in ("lazy", "eager", "off"):
+            raise ValueError("prediction_cache: 'lazy', 'eager' or 'off'")
+        super().__init__(value)
+
+    @classmethod
+    def value(cls):
+        return cls._stack[-1]

@@ -12,6 +12,18 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _eager_cache(request):
+    """The tests below count hits and misses from the FIRST eval call: they run with settings.prediction_cache("eager"); the lazy
+    default (cache built on the second call with unchanged state) has its own test."""
+    if "lazy" in request.node.name:
+        yield
+        return
+    from projectedlmc import settings
+    with settings.prediction_cache("eager"):
+        yield
+
+
 def _model(n=700, d=3, p=5, q=3, seed=0, dtype=torch.float64, **kw):
     import projectedlmc as plmc
     g = torch.Generator().manual_seed(seed)
@@ -142,6 +154,42 @@ def test_kinv_grad_reads_the_planes_of_a_sweep_that_kept_its_planes():
         grads.append(grad.cpu())
     assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0
     assert torch.equal(grads[0], grads[1]), (grads[0] - grads[1]).abs().max()
+
+
+def test_lazy_default_builds_the_cache_on_the_second_call():
+    """Default settings.prediction_cache("lazy"): a single prediction runs the plain augmented sweep from the shared
+    workspace pool and keeps nothing; the second call with unchanged state builds the factorisation with the inverse factor; the third
+    is a hit.  All three equal the oracle; clear_prediction_cache() and "off" behave as named."""
+    from oracle import projected as oproj
+    from projectedlmc import settings
+    from _bridge import oracle_params
+    m, X, Y = _model(dtype=torch.float64, BDN=False)
+    P = oracle_params(m)
+    g = torch.Generator().manual_seed(7)
+    Xs = 2 * torch.rand(200, 3, generator=g, dtype=torch.float64) - 1
+    mean, cov = oproj.task_posterior(P, X, Y, Xs)
+    var = torch.diagonal(cov).reshape(Xs.shape[0], -1)
+    m = m.to(DEV).eval()
+    c = m._prediction_cache()
+    outs = []
+    with torch.no_grad():
+        outs.append(m(Xs.to(DEV)))
+        assert c.ws is None and (c.hits, c.misses) == (0, 1)
+        outs.append(m(Xs.to(DEV)))
+        assert c.ws is not None and c.ws.with_inverse and (c.hits, c.misses) == (0, 2)
+        outs.append(m(Xs.to(DEV)))
+        assert (c.hits, c.misses) == (1, 2)
+        m.clear_prediction_cache()
+        assert c.ws is None
+        outs.append(m(Xs.to(DEV)))
+        assert c.ws is None
+        with settings.prediction_cache("off"):
+            outs.append(m(Xs.to(DEV)))
+            outs.append(m(Xs.to(DEV)))
+            assert c.ws is None
+    for o in outs:
+        assert (o.mean.cpu() - mean).abs().max() < 1e-8 * max(1.0, float(mean.abs().max()))
+        assert (o.variance.cpu() - var).abs().max() < 1e-8 * max(1.0, float(var.abs().max()))
 
 
 def test_cache_is_dropped_when_the_model_changes():
