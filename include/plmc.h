@@ -397,9 +397,9 @@ int plmc_qr_small_f64(const double *A, int m, int n, int64_t lda, double *Q, int
  * sixteen ordering events for the look-ahead in plmc_potrf_* (created on first use, never destroyed), each bound to the
  * caller stream that used it last.  Sweeps queued on one stream share a set (stream order protects it); sweeps from two
  * streams get a set each and may overlap on the device (their buffers must differ); a third stream takes over the least
- * recently used set and waits (stream-side, an event) for that set's last sweep.  Calls from several host THREADS on one
- * device must not overlap (they would race on this bookkeeping); different devices are independent.  The Python layer
- * calls from one thread per process.
+ * recently used set and waits (stream-side, an event) for that set's last sweep.  Calls from several host THREADS are
+ * serialised by one library-wide lock while they enqueue (the kernels overlap on the device as their streams allow); each
+ * thread keeps its own choice of sweep set.  The Python layer calls from one thread per process.
  * Dev knobs are environment variables read once per process (PLMC_HALF_TILES, PLMC_GRP, PLMC_KINV_ORDER,
  * PLMC_SERIAL, PLMC_BULK_LDS, PLMC_CHAIN, PLMC_CHAIN_NW, PLMC_CHAIN_EDGE); plmc_dev_reload_knobs() re-reads them (tests and bench.py change one and reload).  They change
  * schedules; PLMC_GRP also changes the depth of the updates and with it the rounding.  PLMC_SPLIT (0, 2, 3) selects the

@@ -1,5 +1,6 @@
 // api.hip -- library identification, error text, and the optional per-kernel HIP-event profiler.
 #include <stdlib.h>
+#include <mutex>
 #include <vector>
 
 #include "api_common.hpp"
@@ -30,6 +31,14 @@ static hipEvent_t get_event() {
   return e;
 }
 
+// One lock for the process-global bookkeeping (profiler record, sweep contexts, knobs): every entry point that launches
+// profiled kernels holds it while it ENQUEUES (a ProfScope takes it for its lifetime; recursive: scopes nest), so calls from
+// several host threads serialise their enqueueing instead of racing -- the kernels themselves still overlap on the device as the
+// streams allow ("documented, not enforced").
+static std::recursive_mutex g_api_mutex;
+void api_lock() { g_api_mutex.lock(); }
+void api_unlock() { g_api_mutex.unlock(); }
+
 static Knobs g_knobs;
 static bool g_knobs_loaded = false;
 static void load_knobs() {
@@ -48,7 +57,10 @@ static void load_knobs() {
   g_knobs_loaded = true;
 }
 const Knobs &knobs() {
-  if (!g_knobs_loaded) load_knobs();
+  if (!g_knobs_loaded) {
+    std::lock_guard<std::recursive_mutex> lk(g_api_mutex);
+    if (!g_knobs_loaded) load_knobs();
+  }
   return g_knobs;
 }
 
@@ -191,6 +203,7 @@ template <typename T, bool BF16 = false> static int mfma_rate_impl(void *sink, i
 }
 
 ProfScope::ProfScope(int id, hipStream_t st, double flops, double bytes) : idx_(-1), st_(st) {
+  api_lock();
   if (!((g_prof_mask >> id) & 1u) || g_recs.size() >= (1u << 20)) return;
   ProfRec r{id, get_event(), get_event(), flops, bytes};
   if (!r.a || !r.b) return;
@@ -200,6 +213,7 @@ ProfScope::ProfScope(int id, hipStream_t st, double flops, double bytes) : idx_(
 }
 ProfScope::~ProfScope() {
   if (idx_ >= 0) (void)hipEventRecord(g_recs[idx_].b, st_);
+  api_unlock();
 }
 }  // namespace plmc
 
@@ -211,6 +225,7 @@ int plmc_max_dim(void) { return plmc::MAX_DIM; }
 const char *plmc_last_error(void) { return plmc::err_buf(); }
 
 int plmc_prof_enable(int on) {
+  std::lock_guard<std::recursive_mutex> lk(plmc::g_api_mutex);
   const unsigned prev = plmc::g_prof_mask, all = (1u << plmc::PK_COUNT) - 1u;
   plmc::g_prof_mask = on == 0 ? 0u : (on == 1 ? all : ((unsigned)on >> 1) & all);
   return prev == 0 ? 0 : (prev == all ? 1 : (int)(prev << 1));
@@ -219,11 +234,16 @@ int plmc_prof_mfma_rate(int kind, void *sink, int64_t sink_bytes, double *tflops
   if (kind == 2) return plmc::mfma_rate_impl<float, true>(sink, sink_bytes, tflops);
   return kind ? plmc::mfma_rate_impl<double>(sink, sink_bytes, tflops) : plmc::mfma_rate_impl<float>(sink, sink_bytes, tflops);
 }
-int plmc_dev_reload_knobs(void) { plmc::load_knobs(); return 0; }
+int plmc_dev_reload_knobs(void) {
+  std::lock_guard<std::recursive_mutex> lk(plmc::g_api_mutex);
+  plmc::load_knobs();
+  return 0;
+}
 int plmc_prof_kernels(void) { return plmc::PK_COUNT; }
 const char *plmc_prof_name(int id) { return (id >= 0 && id < plmc::PK_COUNT) ? plmc::kProfNames[id] : ""; }
 int plmc_prof_collect(double *ms, int64_t *launches, double *flops, double *bytes) {
   using namespace plmc;
+  std::lock_guard<std::recursive_mutex> lk(g_api_mutex);
   for (int i = 0; i < PK_COUNT; ++i) { ms[i] = 0; launches[i] = 0; flops[i] = 0; bytes[i] = 0; }
   for (auto &r : g_recs) {
     float t = 0.f;

@@ -300,6 +300,60 @@ def test_sweeps_from_three_caller_streams_overlap_safely(eng):
     torch.cuda.empty_cache()
 
 
+def test_sweeps_from_two_host_threads_are_serialised_by_the_library(eng):
+    """the library's process-global bookkeeping (sweep contexts, profiler record) was documented as single-threaded
+    but not enforced.  Entry points now hold one library-wide lock while they enqueue.  Two host threads (ctypes releases the GIL
+    during a call) factorise their own problems on their own streams, many times, with the profiler recording: every factor buffer
+    equals the one the same problem gives alone, bit for bit."""
+    import threading
+    from projectedlmc import _hip
+    n, q, d, dtype = 2304, 2, 5, torch.float32
+    g = torch.Generator().manual_seed(21)
+    X = (2 * torch.rand(n, d, generator=g, dtype=dtype) - 1).to(DEV)
+    it = torch.int32
+    probs = []
+    for k in range(2):
+        y = torch.randn(q, n, generator=g, dtype=dtype).to(DEV)
+        ell = (0.5 + 0.2 * k + 0.3 * torch.rand(q, d, generator=g, dtype=dtype)).to(DEV)
+        noise = (0.05 + 0.1 * k + 0.2 * torch.rand(q, generator=g, dtype=dtype)).to(DEV)
+        probs.append((ell, noise, y.reshape(q, 1, n).contiguous(), eng.Workspace(n, q, 1, dtype, torch.device(DEV), True)))
+    ref = []
+    for ell, noise, y, ws in probs:
+        eng.factorize("matern52", X, ell, None, noise, y, ws)
+        torch.cuda.synchronize()
+        ref.append((ws.A.view(it).clone(), ws.logdet.clone()))
+    errors = []
+
+    def worker(k):
+        try:
+            ell, noise, y, ws = probs[k]
+            s = torch.cuda.Stream(DEV)
+            for rep in range(12):
+                with torch.cuda.stream(s):
+                    eng.factorize("matern52", X, ell, None, noise, y, ws)
+                s.synchronize()
+                if int((ws.A.view(it) != ref[k][0]).sum()) != 0 or not torch.equal(ws.logdet, ref[k][1]):
+                    errors.append((k, rep))
+        except Exception as exc:                           # a worker must not die silently
+            errors.append((k, repr(exc)))
+
+    _hip.prof_enable(True)
+    try:
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        torch.cuda.synchronize()
+        stats = _hip.prof_collect()
+    finally:
+        _hip.prof_enable(False)
+    assert not errors, errors
+    assert stats["sweep_total"]["launches"] == 24
+    del probs, ref
+    torch.cuda.empty_cache()
+
+
 def test_training_step_is_deterministic_at_metric_shape(eng):
     """Whole MLL + gradient evaluation (sweep, alpha, fused K^-1 + gradient kernel on its own stream) repeated at the
     metric shape: log-probs and every gradient bit-identical."""
