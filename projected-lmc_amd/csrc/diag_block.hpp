@@ -315,13 +315,13 @@ __global__ __launch_bounds__(NT) void k_diag(T *A, int64_t lda, int64_t strideA,
 // was not positive left NaN / inf / <= 0 behind; info = 1 + index of the first one, 0 if none).
 // grid (q), 256 threads; fixed-order reduction.
 // `chain_ctl` (optional): the control words of the resident chain kernel in the sweep's scratch (potrf.hip, k_chain), one
-// set every `ctl_stride` elements: a raised abort word (a bounded spin ran out -- never seen; it would mean a workgroup of the
+// set every `ctl_stride` elements for `nlat` latents (a launch of the chain kernel uses the set of its first latent): a raised abort word (a bounded spin ran out -- never seen; it would mean a workgroup of the
 // chain was not resident) is reported as info = PLMC_INFO_CHAIN_ABORT instead of a pivot index.
 constexpr int INFO_CHAIN_ABORT = 0x7ffffff0;
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_logdet(const T *__restrict__ A, int64_t n_pad, int64_t lda, int64_t strideA,
                                                       double *__restrict__ logdet, int *__restrict__ info, const T *chain_ctl = nullptr,
-                                                      int64_t ctl_stride = 0) {
+                                                      int64_t ctl_stride = 0, int nlat = 0) {
   __shared__ double red[NTHREADS];
   __shared__ int redb[NTHREADS];
   const int lat = blockIdx.x, tid = threadIdx.x;
@@ -344,7 +344,11 @@ __global__ __launch_bounds__(NTHREADS) void k_logdet(const T *__restrict__ A, in
   if (tid == 0) {
     logdet[lat] = red[0];
     info[lat] = redb[0] == 0x7fffffff ? 0 : redb[0];
-    if (chain_ctl && reinterpret_cast<const int *>(chain_ctl + (int64_t)lat * ctl_stride)[1] != 0) info[lat] = INFO_CHAIN_ABORT;
+    if (chain_ctl) {                       // any launch of the chain kernel that gave up poisons the whole batch
+      bool ab = false;
+      for (int l = 0; l < nlat; ++l) ab = ab || reinterpret_cast<const int *>(chain_ctl + (int64_t)l * ctl_stride)[1] != 0;
+      if (ab) info[lat] = INFO_CHAIN_ABORT;
+    }
   }
 }
 

@@ -152,8 +152,10 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_update(T *A, in
 //    row r: panel tiles P <- V_r^T P of row r, U tiles right of the diagonal and W tiles left of it; then the rank-128 updates
 //    C -= P_i^T P_j of every tile below, W tiles of column r being first touches C = -P^T W_rr), latent fastest.
 // That list is a topological order of the dependency graph and a ticket is only ever held by a resident workgroup, so the
-// lowest unfinished operation can always run: deadlock-free for ANY number of resident pool workgroups, with no assumption on
-// placement or dispatch order.  Dependencies = version counters per tile (`cnt`, per latent: 8 x 8 U tiles, 8 x 8 W tiles): tile
+// lowest unfinished operation can always run -- deadlock-free for ANY number of resident pool workgroups, with no assumption on
+// placement or dispatch order -- PROVIDED the q critical workgroups of the launch are resident: they are dispatched first
+// (lowest block indices) and the host keeps q <= CHAIN_QB per launch (potrf_impl) so that they always fit.  Every wait is
+// bounded besides (chain_wait).  Dependencies = version counters per tile (`cnt`, per latent: 8 x 8 U tiles, 8 x 8 W tiles): tile
 // U(i,j) is final at version i + 1 (i updates + its panel solve / factorisation), W(i,c) at i - c + 1.  Every tile receives its
 // operations in the order of the launches, each the same K = 128 product: the results are bit-identical to the launch-per-step chain.
 // Counters live in the pad column of each latent's group scratch Wg (row 0: the 128 counters; row 1 of latent 0: finished
@@ -1117,7 +1119,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   }
   auto finish = [&]() {
     hipLaunchKernelGGL(k_logdet<T>, dim3(q), dim3(NTHREADS), 0, st, (const T *)A, n_pad, lda, strideA, logdet, info,
-                       (const T *)(Wg + (int64_t)LDG + (int64_t)GMAX * NB), (int64_t)0);    // (the chain kernel's abort word: latent 0's)
+                       (const T *)(Wg + (int64_t)LDG + (int64_t)GMAX * NB), strideV, q);    // (the chain kernel's abort words: one per launch, at its first latent)
     return launch_status("potrf_impl");
   };
   // Group boundaries.  Large groups divide the read-modify-write traffic of the trailing matrix by G and put
@@ -1142,7 +1144,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // and group of 8 (12-16 us each).  The pool is sized to keep up with the critical workgroups' ~40 us per block row without
   // holding more CUs than that (a chain workgroup does not fit on a CU beside a 228-register bulk workgroup); PLMC_CHAIN_NW
   // overrides, PLMC_CHAIN=0 brings the launches back.
-  const int chain_pool = kn.chain_nw > 0 ? (kn.chain_nw < 240 ? kn.chain_nw : 240) : (q >= 8 ? 80 : (q >= 4 ? 44 : (q >= 2 ? 36 : 31)));
+  constexpr int CHAIN_QB = 32;
+  const int chain_pool = kn.chain_nw > 0 ? (kn.chain_nw < 200 ? kn.chain_nw : 200) : (q >= 8 ? 80 : (q >= 4 ? 44 : (q >= 2 ? 36 : 31)));   // (PLMC_CHAIN_NW > 80: dev only)
   auto chain = [&](int gi, hipStream_t s) {
     const int g0 = G0(gi), g1 = G0(gi + 1);
     if (kn.chain) {
@@ -1153,7 +1156,15 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       // 18.22 / 9.82 with one size for all groups: the extra workgroups mostly wait on the per-latent dependency fronts.)
       const bool edge = gi == 0 || gi + 2 >= ng;
       const int pool = (edge && kn.chain_edge > 0) ? kn.chain_edge : chain_pool;
-      hipLaunchKernelGGL((k_chain<T>), dim3(q + (G > 1 ? pool : 0)), dim3(CH_NT), 0, s, A, lda, strideA, g0, G, Vd, strideV, Wg, strideV, q);
+      // RESIDENCY: the critical workgroups of a launch must all be resident (the pool's tickets wait for them), and a chain workgroup
+      // needs a CU of its own.  A launch therefore carries at most CHAIN_QB latents: CHAIN_QB + pool <= 112 workgroups, so that even
+      // the two sweeps that may be in flight at once (two caller streams, api.hip) fit the 256 CUs together; more latents go as
+      // further launches behind it on the same stream (their control words: those of the launch's first latent).
+      for (int l0 = 0; l0 < q; l0 += CHAIN_QB) {
+        const int ql = q - l0 < CHAIN_QB ? q - l0 : CHAIN_QB;
+        hipLaunchKernelGGL((k_chain<T>), dim3(ql + (G > 1 ? pool : 0)), dim3(CH_NT), 0, s, A + (int64_t)l0 * strideA, lda, strideA, g0, G,
+                           Vd + (int64_t)l0 * strideV, strideV, Wg + (int64_t)l0 * strideV, strideV, ql);
+      }
       return;
     }
     for (int r = g0; r < g1; ++r) {

@@ -372,3 +372,33 @@ def test_training_step_is_deterministic_at_metric_shape(eng):
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
     assert bool(torch.isfinite(outs[0][0]).all())
+
+
+def test_many_latents_go_through_the_chain_kernel_in_batches(eng):
+    """The resident chain kernel carries at most 32 latents per launch (its critical workgroups must all be resident); q = 70 small
+    problems of two groups each run as three launches per group.  Same bits as the launch-per-step chain, log-probs against a
+    per-latent fp64 torch reference."""
+    from projectedlmc import _hip
+    n, q, d, dtype = 1300, 70, 3, torch.float64
+    g = torch.Generator().manual_seed(8)
+    X = (2 * torch.rand(n, d, generator=g, dtype=dtype) - 1).to(DEV)
+    y = torch.randn(q, n, generator=g, dtype=dtype).to(DEV)
+    ell = (0.4 + 0.6 * torch.rand(q, d, generator=g, dtype=dtype)).to(DEV)
+    noise = (0.05 + 0.3 * torch.rand(q, generator=g, dtype=dtype)).to(DEV)
+    ws = eng.Workspace(n, q, 1, dtype, torch.device(DEV), True)
+
+    def factor():
+        eng.factorize("rbf", X, ell, None, noise, y.reshape(q, 1, n), ws)
+        torch.cuda.synchronize()
+        return ws.A.view(torch.int64).clone(), ws.logdet.clone(), ws.info.clone()
+
+    A1, ld1, info1 = factor()
+    with _hip.knob("PLMC_CHAIN", "0"):
+        A0, ld0, info0 = factor()
+    assert not bool(info1.any()) and int((A1 != A0).sum()) == 0 and torch.equal(ld1, ld0)
+    for l in (0, 31, 32, 69):
+        r2 = torch.cdist(X / ell[l], X / ell[l]) ** 2
+        K = torch.exp(-0.5 * r2) + noise[l] * torch.eye(n, dtype=dtype, device=DEV)
+        assert abs(float(torch.logdet(K)) - float(ld1[l])) < 1e-8 * abs(float(ld1[l]))
+    del ws, A0, A1
+    torch.cuda.empty_cache()
