@@ -1094,6 +1094,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       ColMap<T> cb = cm, ca = cm;
       if (aug_fp32) { cb.Taug = 0; ca.nU = 0; ca.nW = 0; }
       const int nb_ = cb.nU + cb.Taug + cb.nW, nm = (G + 1) / 2;
+      // (round 4: one macro row per workgroup, heaviest first, instead of heavy + light pairs for the rest panel too: 17.86-17.89
+      // against 17.82-17.84 ms/step at q = 8, level at q = 4 -- the pairing stays)
       if (nb_ > 0)
         hipLaunchKernelGGL((k_gpanel_bf3<SS>), dim3(nb_, head ? nm : (nm + 1) / 2, q), dim3(B3_NT), 0, s, A, lda, strideA, g0, G, cb,
                            (const unsigned short *)VgP2[Vg == Vg2[1]], pl_lat, (const unsigned short *)Praw, pl_lat, planes(g0), pl_lat, wcol0,
