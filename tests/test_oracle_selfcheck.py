@@ -214,3 +214,41 @@ def test_lmc_exact_mll_rank1_equals_projected_dense():
     K = gm.kernel_matrix("rbf", X, X, ell)
     a, s, b, t = 3, 1, 7, 2
     assert torch.allclose(C[a * 3 + s, b * 3 + t], (K[:, a, b] * B[:, s, t]).sum())
+
+
+@pytest.mark.parametrize("ortho_param", ["matrix_exp", "cayley", "householder"])
+@pytest.mark.parametrize("shape", [(6, 6), (6, 2)])
+def test_restated_orthogonal_map_equals_torchs_parametrisation(ortho_param, shape):
+    """`oracle.projected.orthogonal_map` restates what torch.nn.utils.parametrizations.orthogonal evaluates (the third-party
+    arithmetic behind `bulk=False`, projected_lmc.py:963-965): element for element against torch's own module on perturbed
+    parameters, square (mode 'Q_plus') and tall (mode 'Q') matrices."""
+    torch.manual_seed(2)
+    lin = torch.nn.Linear(shape[1], shape[0], bias=False).double()            # weight: shape[0] x shape[1]
+    Q0, _ = torch.linalg.qr(torch.randn(shape[0], shape[0]))
+    with torch.no_grad():
+        lin.weight.copy_(Q0[:, :shape[1]])
+    lin = torch.nn.utils.parametrizations.orthogonal(lin, name="weight", orthogonal_map=ortho_param,
+                                                     use_trivialization=(ortho_param != "householder"))
+    orth = lin.parametrizations.weight[0]
+    with torch.no_grad():
+        orig = lin.parametrizations.weight.original
+        pert = 0.3 * torch.randn(orig.shape)
+        if ortho_param == "householder":
+            pert = pert.tril(-1)                                                # the signed diagonal is not a free parameter
+        orig.add_(pert)
+    base = getattr(orth, "base", None)
+    got = pj.orthogonal_map(lin.parametrizations.weight.original.detach(), None if base is None else base.detach(), ortho_param)
+    assert torch.allclose(got, lin.weight.detach(), atol=1e-13)
+    assert torch.allclose(got.T @ got, torch.eye(shape[1]), atol=1e-12)
+
+
+def test_prediction_cache_setting_rejects_unknown_modes():
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "projected-lmc_amd"))
+    from projectedlmc import settings
+    assert settings.prediction_cache.value() == "lazy"
+    with settings.prediction_cache("off"):
+        assert settings.prediction_cache.value() == "off"
+    assert settings.prediction_cache.value() == "lazy"
+    with pytest.raises(ValueError):
+        settings.prediction_cache("sometimes")
