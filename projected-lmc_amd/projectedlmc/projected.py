@@ -227,6 +227,10 @@ class ProjectedGPModel(ExactGPModel):
 
     def full_noise_covariance(self):
         """Task-space noise Sigma (p x p) (projected_lmc.py:1026-1060)."""
+        with parametrize.cached():
+            return self._full_noise_covariance()
+
+    def _full_noise_covariance(self):
         Q, R, Q_orth = self.lmc_coefficients.QR()
         QRm = Q @ R
         sp = self.projected_noise()
@@ -280,6 +284,10 @@ class ProjectedGPModel(ExactGPModel):
         return MultivariateNormal(self.mean_module(x), self.covar_module(x))
 
     def _latent_posterior(self, x, full_cov=False):
+        with parametrize.cached():
+            return self._latent_posterior_body(x, full_cov)
+
+    def _latent_posterior_body(self, x, full_cov=False):
         tx = self.train_inputs[0]
         lazy = self.covar_module(tx)
         ytil = self.project_data(self.train_y).detach()
@@ -388,6 +396,12 @@ class ProjectedLMCmll(ExactMarginalLogLikelihood):
             warnings.warn("A not p.d., added jitter of %.1e to the diagonal" % jit, RuntimeWarning)
 
     def _forward_once(self, latent_function_dist, target, inputs=None, *params):
+        # every parametrised tensor (log_B_tilde / B_tilde_inv_chol; with bulk=False the orthogonal Q_plus -- a matrix exponential --
+        # and R) is evaluated ONCE per forward pass instead of at every attribute access (same values, one autograd node each)
+        with parametrize.cached():
+            return self._forward_body(latent_function_dist, target, inputs, *params)
+
+    def _forward_body(self, latent_function_dist, target, inputs=None, *params):
         model = self.model
         num_data = latent_function_dist.event_shape.numel()
         # (reference order :1200-1201 is projection, then likelihood; the two are independent.  The hyper-parameter
