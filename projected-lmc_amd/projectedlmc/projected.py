@@ -363,6 +363,65 @@ class _DiagonalTaskCovariance:
         raise RuntimeError("only marginal variances are available on the sharded prediction path")
 
 
+class _LateCheck:
+    """State of one training step's late pivot check (settings.late_pivot_check)."""
+
+    def __init__(self, mll, dc, args):
+        self.mll, self.dc, self.args = mll, dc, args
+        self.done = False
+        self.result = None
+        self.snapshot = None
+
+    def params(self):
+        return [p for p in self.mll.parameters() if p.requires_grad]
+
+    def begin_backward(self, gout):
+        # what the parameters' .grad held before this backward pass: restored if the pass has to be redone (a clone only where
+        # gradients are being accumulated across calls; zero_grad() leaves None)
+        if self.snapshot is None and not self.done:
+            self.snapshot = [(p, None if p.grad is None else p.grad.clone()) for p in self.params()]
+            self.gout = gout
+            torch.autograd.Variable._execution_engine.queue_callback(self.end_backward)
+
+    def end_backward(self):
+        if self.done:
+            return
+        self.done = True
+        snapshot, self.snapshot = self.snapshot, None
+        mll, args, self.mll, self.args = self.mll, self.args, None, None
+        if not self.dc.failed():                                  # waits for the copy behind the sweep, not for the GPU
+            return
+        warnings.warn("non-positive-definite matrix found behind the backward pass (settings.late_pivot_check): forward and backward "
+                      "are redone with jitter; the tensor ProjectedLMCmll returned is overwritten with the jittered value, tensors "
+                      "computed from it before backward() keep the failed pass's value", RuntimeWarning)
+        for p, g in snapshot:
+            p.grad = g
+        with torch.enable_grad():
+            # the graph behind the prior (the constrained hyper-parameters) went with the backward pass that just ended: build it
+            # again -- in training mode the prior is the model at its training inputs
+            args = (mll.model(*mll.model.train_inputs),) + tuple(args[1:])
+            res = mll._jitter_ladder(args, self.dc)
+            res.backward(self.gout)
+        out = self.result() if self.result is not None else None
+        if out is not None:
+            with torch.no_grad():
+                out.copy_(res.detach())
+
+
+class _LatePivotCheck(torch.autograd.Function):
+    """Identity on the loss; its backward (the first node of the backward pass) arms the end-of-backward check."""
+
+    @staticmethod
+    def forward(ctx, loss, late):
+        ctx.late = late
+        return loss.view_as(loss)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.late.begin_backward(g)
+        return g, None
+
+
 class ProjectedLMCmll(ExactMarginalLogLikelihood):
     """Loss of the ProjectedGPModel (projected_lmc.py:1158-1241): sum of the q latent exact-GP
     log-likelihoods of the projected data (HIP engine) / n, plus the projection terms."""
@@ -382,18 +441,45 @@ class ProjectedLMCmll(ExactMarginalLogLikelihood):
             raise RuntimeError("ExactMarginalLogLikelihood can only operate on Gaussian random variables")
         if not (settings.check_cholesky.on() and target.is_cuda) or os.environ.get("PLMC_DEFER_CHECK", "1") == "0":
             return self._forward_once(latent_function_dist, target, inputs, *params)
-        base, tries = settings.cholesky_jitter.value(target.dtype), settings.cholesky_max_tries.value()
+        self._settle_late_check()
+        args = (latent_function_dist, target, inputs) + tuple(params)
+        with _engine.deferred_pivot_checks(0.0) as dc:
+            res = self._forward_once(*args)
+        if (settings.late_pivot_check.on() and os.environ.get("PLMC_LATE_CHECK", "1") != "0" and torch.is_grad_enabled()
+                and res.requires_grad and self.model.training):
+            # training step: the check moves behind the backward pass (settings.late_pivot_check)
+            late = _LateCheck(self, dc, args)
+            res = _LatePivotCheck.apply(res, late)
+            late.result = weakref.ref(res)
+            self._late = late
+            return res
+        if not dc.failed():
+            return res
+        return self._jitter_ladder(args, dc)
+
+    def _jitter_ladder(self, args, dc):
+        """The forward pass again with jitter 1e-6 (fp32) x 10^i -- gpytorch's psd_safe_cholesky [gpytorch-knowledge]."""
+        base, tries = settings.cholesky_jitter.value(args[1].dtype), settings.cholesky_max_tries.value()
         jit = 0.0
-        for i in range(tries + 1):
-            with _engine.deferred_pivot_checks(jit) as dc:
-                res = self._forward_once(latent_function_dist, target, inputs, *params)
-            if not dc.failed():
-                return res
-            if i == tries:
-                raise RuntimeError("Matrix not positive definite after repeatedly adding jitter up to %.1e "
-                                   "(first failing pivot per latent: %s)" % (jit, dc.first_bad))
+        for i in range(tries):
             jit = base * (10 ** i)
             warnings.warn("A not p.d., added jitter of %.1e to the diagonal" % jit, RuntimeWarning)
+            with _engine.deferred_pivot_checks(jit) as dc:
+                res = self._forward_once(*args)
+            if not dc.failed():
+                return res
+        raise RuntimeError("Matrix not positive definite after repeatedly adding jitter up to %.1e "
+                           "(first failing pivot per latent: %s)" % (jit, dc.first_bad))
+
+    def _settle_late_check(self):
+        """A late check whose backward pass never ran (a loss evaluated with gradients on and dropped) is looked at now: by the
+        next forward call its copy has long landed."""
+        late, self._late = getattr(self, "_late", None), None
+        if late is not None and not late.done:
+            late.done = True
+            if late.dc.failed():
+                warnings.warn("the previous loss evaluation met a non-positive-definite matrix and was never back-propagated: "
+                              "its value was computed without jitter (not finite)", RuntimeWarning)
 
     def _forward_once(self, latent_function_dist, target, inputs=None, *params):
         # every parametrised tensor (log_B_tilde / B_tilde_inv_chol; with bulk=False the orthogonal Q_plus -- a matrix exponential --

@@ -55,6 +55,26 @@ class check_cholesky(_Value):
         return cls._stack[-1]
 
 
+class late_pivot_check(_Value):
+    """late_pivot_check(True | False): in a training step (ProjectedLMCmll.forward with gradients on) the pivot check of the
+    latent factorisation is looked at when the BACKWARD pass has been queued, not at the end of the forward pass: the host
+    queues the projection terms, the backward pass and (after the check) the optimiser step while the sweep runs, instead of
+    sitting the sweep out first.  Nothing is skipped: on a non-PD pivot the gradients this backward pass accumulated are taken
+    back and the jitter ladder (gpytorch's psd_safe_cholesky, same warnings, same final error) redoes forward and backward
+    before `backward()` returns; the tensor ProjectedLMCmll returned is overwritten with the jittered value (a tensor computed from
+    it BEFORE backward(), e.g. `loss = -mll(...)`, keeps the failed pass's value for that one step -- a warning says so; gradients
+    and parameters are those of the jittered pass).  Assumes the parameters' gradients of this pass come through this loss only
+    (the failed pass's accumulation is undone by restoring what .grad held when backward began).  A forward pass whose backward
+    never runs is checked at the next forward call.  False (or PLMC_LATE_CHECK=0): the check sits at the end of the forward
+    pass, as in round 3.  Measured, metric shape: one latent per rank 5.32 -> 4.81 ms per step (the host used to sit out the
+    3.5 ms sweep before queueing ~110 launches of loss terms and backward pass); q = 8: 17.85 -> 17.81."""
+    _stack = [True]
+
+    @classmethod
+    def on(cls):
+        return cls._stack[-1]
+
+
 class prediction_cache(_Value):
     """prediction_cache("lazy" | "eager" | "off"): when an eval-mode model builds the factorisation it keeps between prediction
     calls (_engine.PosteriorCache; gpytorch's prediction strategy keeps its own from the first call).  "lazy" (default): on the

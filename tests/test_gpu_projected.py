@@ -1,5 +1,6 @@
 """GPU parity of the model-level API (ProjectedGPModel + ProjectedLMCmll, ExactGPModel + ExactMLL)
 against the CPU oracle: loss, gradients w.r.t. every parameter, and eval-mode predictions."""
+import math
 import warnings
 
 import pytest
@@ -325,11 +326,92 @@ def test_deferred_pivot_check_walks_the_same_jitter_ladder(plmc):
     Xd, Yd = X.float().to(DEV), Y.float().to(DEV)
     m.train(); m.likelihood.train()
     mll = plmc.ProjectedLMCmll(m.likelihood, m)
-    with pytest.warns(RuntimeWarning, match="not p.d."):
-        loss = -mll(m(Xd), Yd)
-    loss.backward()
+    with pytest.warns(RuntimeWarning, match="not p.d."):      # in a training step the check may sit behind the backward pass
+        out = mll(m(Xd), Yd)                                    # (settings.late_pivot_check: `out` is then overwritten with the
+        loss = -out                                             # jittered value; tensors derived from it before that are stale)
+        loss.backward()
+    loss = -out.detach()
     assert torch.isfinite(loss)
     assert all(torch.isfinite(prm.grad).all() for prm in m.parameters() if prm.grad is not None)
     with pytest.warns(RuntimeWarning, match="not p.d."):
         direct = -mll._forward_once(m(Xd), Yd)
     assert abs(float(loss.detach()) - float(direct.detach())) <= 1e-5 * abs(float(direct.detach()))
+
+
+def _singular_model(plmc, seed=1):
+    n, d, p, q = 300, 2, 4, 2
+    X, Y = _data(n, d, p, seed=3)
+    torch.manual_seed(seed)
+    m = _model(plmc, X.float(), Y.float(), q, plmc.RBFKernel, noise_thresh=-40., **VARIANTS["PLMC_fast"]).to(DEV)
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if "lengthscale" in name:
+                prm.fill_(5.0)
+            if "raw_noise" in name:
+                prm.fill_(-40.0)
+    m.train(); m.likelihood.train()
+    return m, X.float().to(DEV), Y.float().to(DEV)
+
+
+def test_late_pivot_check_is_the_same_training_step(plmc):
+    """settings.late_pivot_check (default on): the pivot check of a training step sits behind the backward pass.  Healthy
+    matrices: losses and parameters of three AdamW steps are bit-identical to the check at the end of the forward pass.  A
+    non-PD matrix: the gradients of the failed pass are taken back (gradients accumulated BEFORE the pass are kept), the jitter
+    ladder redoes forward and backward inside backward(), and the loss tensor the caller holds ends up with the jittered value:
+    same warnings, same loss, same gradients as with the early check."""
+    from projectedlmc import settings
+
+    def train(late):
+        n, d, p, q = 300, 2, 4, 2
+        X, Y = _data(n, d, p, seed=5)
+        torch.manual_seed(2)
+        m = _model(plmc, X.float(), Y.float(), q, plmc.MaternKernel, **VARIANTS["PLMC_fast"]).to(DEV)
+        m.train(); m.likelihood.train()
+        mll = plmc.ProjectedLMCmll(m.likelihood, m)
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-2)
+        Xd, Yd = X.float().to(DEV), Y.float().to(DEV)
+        losses = []
+        with settings.late_pivot_check(late):
+            for _ in range(3):
+                opt.zero_grad()
+                loss = -mll(m(Xd), Yd)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+        return losses, [prm.detach().clone() for prm in m.parameters()]
+
+    la, pa = train(True)
+    lb, pb = train(False)
+    assert la == lb
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb))
+
+    def failing_step(late):
+        m, Xd, Yd = _singular_model(plmc)
+        mll = plmc.ProjectedLMCmll(m.likelihood, m)
+        for prm in m.parameters():
+            prm.grad = torch.full_like(prm, 0.25)               # gradients already accumulated by an earlier call
+        with settings.late_pivot_check(late), warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            out = mll(m(Xd), Yd)
+            n_fwd = sum("not p.d." in str(w.message) for w in rec)
+            (-out).backward()
+        n_all = sum("not p.d." in str(w.message) for w in rec)
+        return -float(out.detach()), [prm.grad.clone() for prm in m.parameters()], n_fwd, n_all
+
+    l1, g1, f1, a1 = failing_step(True)
+    l0, g0, f0, a0 = failing_step(False)
+    assert f1 == 0 and a1 >= 1                                  # the late check warns from inside backward()
+    assert f0 == a0 == a1                                       # the same rungs of the ladder
+    assert l1 == l0 and math.isfinite(l1)
+    for a, b in zip(g1, g0):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_late_pivot_check_of_a_dropped_loss_is_settled_at_the_next_forward(plmc):
+    """A loss evaluated with gradients on and never back-propagated: its pending check is looked at by the next forward call."""
+    m, Xd, Yd = _singular_model(plmc)
+    mll = plmc.ProjectedLMCmll(m.likelihood, m)
+    _ = mll(m(Xd), Yd)                                          # no backward
+    with pytest.warns(RuntimeWarning, match="never back-propagated"):
+        with torch.no_grad():
+            mll(m(Xd), Yd)
