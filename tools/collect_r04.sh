@@ -11,6 +11,10 @@ echo "collect_profiles rc=$?"
 # what one rank of the N-GPU run executes
 timeout -k 10 300 python tools/time_shard_rank.py 8 4 2 1 2>&1 | grep -v amdgpu.ids > $OUT/${R}_shard_rank_times.txt
 PLMC_CHAIN=0 timeout -k 10 300 python tools/time_shard_rank.py 8 1 2>&1 | grep -v amdgpu.ids | sed 's/^/PLMC_CHAIN=0 /' >> $OUT/${R}_shard_rank_times.txt
+PLMC_LATE_CHECK=0 timeout -k 10 300 python tools/time_shard_rank.py 8 1 2>&1 | grep -v amdgpu.ids | sed 's/^/PLMC_LATE_CHECK=0 /' >> $OUT/${R}_shard_rank_times.txt
+# where the host waits inside one training step (settings.late_pivot_check on / off)
+timeout -k 10 200 python tools/dev/host_phases.py 1 8 2>&1 | grep -v amdgpu.ids > $OUT/${R}_host_phases.txt
+PLMC_LATE_CHECK=0 timeout -k 10 200 python tools/dev/host_phases.py 1 8 2>&1 | grep -v amdgpu.ids >> $OUT/${R}_host_phases.txt
 # critical workgroup of the chain kernel, phase by phase (variant build with -DPLMC_CHAIN_TRACE)
 PLMC_LIB=tools/variants/libplmc_trace.so timeout -k 10 120 python tools/chain_trace.py 1 2>&1 | grep -v amdgpu.ids > $OUT/${R}_chain_trace_q1.txt
 # the other BASELINE configs
@@ -21,4 +25,5 @@ timeout -k 10 300 python tools/time_predict.py 2>&1 | grep -v amdgpu.ids | tail 
 # sweep timelines
 bash tools/run_trace.sh 8 > /dev/null 2>&1; cp $OUT/r3/phases_q8.txt $OUT/${R}_sweep_phases_q8.txt; cp $OUT/r3/tls_q8.txt $OUT/${R}_sweep_timeline_stats_q8.txt
 bash tools/run_trace.sh 1 > /dev/null 2>&1; cp $OUT/r3/phases_q1.txt $OUT/${R}_sweep_phases_q1.txt
+bash tools/run_step_trace.sh 1 > /dev/null 2>&1; cp $OUT/r4/step_q1.txt $OUT/${R}_step_timeline_q1.txt
 echo done
