@@ -328,11 +328,24 @@ __global__ __launch_bounds__(NTHREADS) void k_logdet(const T *__restrict__ A, in
   const T *Al = A + (int64_t)lat * strideA;
   double lg = 0.0;
   int bad = 0x7fffffff;
-  for (int64_t i = tid; i < n_pad; i += NTHREADS) {
-    const T d = Al[i * lda + i];
-    const bool ok = d > T(0) && d < T(3.0e38);
-    if (ok) lg += 2.0 * log((double)d);
-    else bad = (int)i + 1 < bad ? (int)i + 1 : bad;
+  for (int64_t i0 = tid; i0 < n_pad; i0 += 8 * NTHREADS) {       // eight diagonal entries in flight per thread (see k_extract_col)
+    T dv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = i0 + u * NTHREADS;
+      const int64_t ic = i < n_pad ? i : n_pad - 1;
+      dv[u] = Al[ic * lda + ic];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = i0 + u * NTHREADS;
+      if (i < n_pad) {
+        const T d = dv[u];
+        const bool ok = d > T(0) && d < T(3.0e38);
+        if (ok) lg += 2.0 * log((double)d);
+        else bad = (int)i + 1 < bad ? (int)i + 1 : bad;
+      }
+    }
   }
   red[tid] = lg;
   redb[tid] = bad;

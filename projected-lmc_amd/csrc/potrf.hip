@@ -803,10 +803,23 @@ __global__ __launch_bounds__(NTHREADS) void k_extract_col(const T *__restrict__ 
   const int lat = blockIdx.x;
   const T *Al = A + (int64_t)lat * strideA + n_pad + c;
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n_pad; i += NTHREADS) {
-    T v = Al[i * lda];
-    z[(int64_t)lat * n_pad + i] = v;
-    s += (double)v * (double)v;
+  // eight strided loads in flight per thread (clamped row, unconditional: one workgroup per latent walks a column of the factor
+  // buffer, and one load per round trip made this 21 us of the serial path behind the sweep); same summation order
+  for (int64_t i0 = threadIdx.x; i0 < n_pad; i0 += 8 * NTHREADS) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = i0 + u * NTHREADS;
+      v[u] = Al[(i < n_pad ? i : n_pad - 1) * lda];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t i = i0 + u * NTHREADS;
+      if (i < n_pad) {
+        z[(int64_t)lat * n_pad + i] = v[u];
+        s += (double)v[u] * (double)v[u];
+      }
+    }
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -821,47 +834,57 @@ __global__ __launch_bounds__(NTHREADS) void k_extract_col(const T *__restrict__ 
 // 32 row groups (16 fp64) x 32 lanes x 16-byte loads (one full 512-byte row segment per row group and step,
 // 4 rows in flight per thread).  HBM-bound: reads the lower triangle of W once.  With 256 threads a workgroup
 // kept too few bytes in flight, and a single-latent shard has only n_pad / 128 workgroups (0.5 TB/s).
+// CW = the columns one workgroup takes (128, or 32 of a block column for shards of a few latents: four times the workgroups of a
+// quarter of the threads each -- at one latent 64 workgroups put 64 of the 256 CUs to work, 114 us for 134 MB).  A column's sum is
+// built from the same row groups in the same order either way: the results are bit-identical.
 constexpr int WTMV_NT = 1024;
-template <typename T>
-__global__ __launch_bounds__(WTMV_NT) void k_wt_matvec(const T *__restrict__ W, int64_t n_pad, int64_t ldw,
-                                                       int64_t strideW, const T *__restrict__ z,
-                                                       T *__restrict__ alpha) {
+template <typename T, int CW = NB>
+__global__ __launch_bounds__(WTMV_NT * CW / NB) void k_wt_matvec(const T *__restrict__ W, int64_t n_pad, int64_t ldw,
+                                                                 int64_t strideW, const T *__restrict__ z,
+                                                                 T *__restrict__ alpha) {
   using vec_t = typename Traits<T>::vec_t;
   constexpr int EPV = Traits<T>::EPV;
-  constexpr int LPR = 128 / EPV;                 // lanes per row segment (32 fp32 / 64 fp64)
-  constexpr int NRG = WTMV_NT / LPR;             // row groups (32 / 16)
-  __shared__ double red[NRG][NB];
+  constexpr int LPR = CW / EPV;                  // lanes per row segment (CW = 128: 32 fp32 / 64 fp64)
+  constexpr int NRG = WTMV_NT / (NB / EPV);      // row groups (32 / 16), whatever CW
+  __shared__ double red[NRG][CW];
   const int lat = blockIdx.y;
   const int cl = (threadIdx.x % LPR) * EPV, rg = threadIdx.x / LPR;
-  const int64_t col0 = (int64_t)blockIdx.x * NB;
-  const T *Wl = W + (int64_t)lat * strideW + col0 + cl;
+  const int64_t colw = (int64_t)blockIdx.x * CW;                   // first column of this workgroup
+  const int64_t col0 = colw / NB * NB;                             // first row of its block column
+  const T *Wl = W + (int64_t)lat * strideW + colw + cl;
   const T *zl = z + (int64_t)lat * n_pad;
   double s[EPV];
 #pragma unroll
   for (int e = 0; e < EPV; ++e) s[e] = 0.0;
-  for (int64_t l = col0 + rg; l < n_pad; l += 4 * NRG) {
-    vec_t v[4];
-    T zz[4];
+  // rows in flight per thread: what a workgroup keeps in flight bounds its rate (128 rows x 128 bytes = 16 KB per 256-thread workgroup
+  // at 4: 8 GB/s over a 2 us round trip, 125 us for the longest column quarter); a 1024-thread workgroup at 4 is at the CU's fill rate
+  constexpr int U = CW == NB ? 4 : 8;
+  for (int64_t l = col0 + rg; l < n_pad; l += U * NRG) {
+    vec_t v[U];
+    T zz[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
+      // unconditional loads from a clamped row, the multiplier zeroed instead: a predicated load is a branch with a full wait behind
+      // it, and the U loads of a thread went out one round trip after the other (round 4: 114 -> see profiles, one latent)
       const int64_t ll = l + u * NRG;
-      const bool ok = ll < n_pad;
-      v[u] = ok ? *reinterpret_cast<const vec_t *>(Wl + ll * ldw) : vec_t{};
-      zz[u] = ok ? zl[ll] : T(0);
+      const int64_t lc = ll < n_pad ? ll : n_pad - 1;
+      v[u] = *reinterpret_cast<const vec_t *>(Wl + lc * ldw);
+      const T zv = zl[lc];
+      zz[u] = ll < n_pad ? zv : T(0);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int e = 0; e < EPV; ++e) s[e] += (double)v[u][e] * (double)zz[u];
   }
 #pragma unroll
   for (int e = 0; e < EPV; ++e) red[rg][cl + e] = s[e];
   __syncthreads();
-  if (threadIdx.x < NB) {
+  if (threadIdx.x < CW) {
     double t = 0.0;
 #pragma unroll
     for (int g = 0; g < NRG; ++g) t += red[g][threadIdx.x];
-    alpha[(int64_t)lat * n_pad + col0 + threadIdx.x] = (T)t;
+    alpha[(int64_t)lat * n_pad + colw + threadIdx.x] = (T)t;
   }
 }
 
@@ -1484,8 +1507,12 @@ int wt_matvec_impl(const T *W, int64_t n_pad, int64_t ldw, int64_t strideW, cons
   PLMC_REQUIRE(W && z && alpha, "null pointer");
   PLMC_REQUIRE(n_pad > 0 && n_pad % NB == 0, "n_pad must be a multiple of NB");
   ProfScope ps(PK_WTMV, (hipStream_t)stream, q * (double)n_pad * n_pad, q * ((double)n_pad * n_pad / 2) * sizeof(T));
-  hipLaunchKernelGGL(k_wt_matvec<T>, dim3((unsigned)(n_pad / NB), q), dim3(WTMV_NT), 0, (hipStream_t)stream, W,
-                     n_pad, ldw, strideW, z, alpha);
+  if ((int64_t)q * (n_pad / NB) < 128)                  // a shard of one latent: 32-column workgroups (same sums, four times the workgroups)
+    hipLaunchKernelGGL((k_wt_matvec<T, 32>), dim3((unsigned)(n_pad / 32), q), dim3(WTMV_NT / 4), 0, (hipStream_t)stream, W, n_pad, ldw, strideW, z,
+                       alpha);
+  else
+    hipLaunchKernelGGL((k_wt_matvec<T, NB>), dim3((unsigned)(n_pad / NB), q), dim3(WTMV_NT), 0, (hipStream_t)stream, W, n_pad, ldw, strideW, z,
+                       alpha);
   return launch_status(__func__);
 }
 

@@ -299,3 +299,31 @@ def test_non_current_device(eng):
     assert torch.cuda.current_device() == 0
     assert torch.allclose(lp.detach().cpu(), ref[0], rtol=1e-10)
     assert torch.allclose(ell_d.grad.cpu(), ref[1], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_wt_matvec_column_split_is_bit_identical(eng, dt):
+    """alpha = W^T z over the lower block triangle.  A launch with fewer than 128 (latent, block column) pairs uses workgroups of 32
+    columns instead of 128 (four times the workgroups for a one-latent shard); every column's sum is built from the same row groups
+    in the same order, so a latent's result must not depend on how many latents share the launch -- and it must be W^T z."""
+    from projectedlmc import _hip
+    L = _hip.lib()
+    dev = torch.device("cuda:0")
+    n_pad, q = 2048, 8                                        # 16 block columns: q = 8 -> 128 pairs (128-column form), q = 1 -> 16 (32-column form)
+    torch.manual_seed(5)
+    W = torch.randn(q, n_pad, n_pad, dtype=dt, device=dev)
+    z = torch.randn(q, n_pad, dtype=dt, device=dev)
+    st = _hip.stream_ptr(dev)
+    batch = torch.zeros(q, n_pad, dtype=dt, device=dev)
+    L.call("plmc_wt_matvec", dt, _hip.ptr(W), n_pad, n_pad, n_pad * n_pad, _hip.ptr(z), _hip.ptr(batch), q, st)
+    single = torch.zeros(q, n_pad, dtype=dt, device=dev)
+    for i in range(q):
+        L.call("plmc_wt_matvec", dt, _hip.ptr(W[i]), n_pad, n_pad, n_pad * n_pad, _hip.ptr(z[i]), _hip.ptr(single[i]), 1, st)
+    torch.cuda.synchronize()
+    assert torch.equal(batch, single)
+    # reference: rows l >= the first row of column i's block (what the kernel reads of a lower-triangular W stored with full blocks)
+    blk = torch.arange(n_pad, device=dev) // 128
+    mask = (blk[:, None] >= blk[None, :]).to(torch.float64)    # [l, i]
+    want = torch.einsum("qli,ql->qi", W.double() * mask, z.double())
+    tol = 1e-12 if dt == torch.float64 else 2e-6
+    assert (batch.double() - want).abs().max() <= tol * want.abs().max()
