@@ -33,21 +33,25 @@ __global__ __launch_bounds__(NTHREADS) void k_posterior_moments(const T *__restr
     for (int64_t r0 = rg; r0 < n_pad; r0 += RG * UNR) {
       vec_t v[UNR];
       T z[UNR];
+      // unconditional loads from a clamped row (a predicated load compiles to a branch with a full wait behind it: the UNR loads
+      // of a thread then go out one round trip at a time -- k_wt_matvec, potrf.hip); rows beyond n_pad contribute exact zeros
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int64_t r = r0 + RG * u;
-        const bool ok = r < n_pad;
-        v[u] = ok ? *reinterpret_cast<const vec_t *>(Z + r * lda + c0) : vec_t{};
-        z[u] = ok ? Z[r * lda] : T(0);
+        const int64_t rc = r < n_pad ? r : n_pad - 1;
+        v[u] = *reinterpret_cast<const vec_t *>(Z + rc * lda + c0);
+        z[u] = Z[rc * lda];
       }
 #pragma unroll
-      for (int u = 0; u < UNR; ++u)
+      for (int u = 0; u < UNR; ++u) {
+        const bool ok = r0 + RG * u < n_pad;
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
-          const double x = (double)v[u][e];
-          m[e] += x * (double)z[u];
+          const double x = ok ? (double)v[u][e] : 0.0;
+          m[e] += x * (ok ? (double)z[u] : 0.0);
           v2[e] += x * x;
         }
+      }
     }
   }
 #pragma unroll

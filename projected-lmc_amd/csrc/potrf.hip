@@ -892,10 +892,19 @@ __global__ __launch_bounds__(WTMV_NT) void k_w_diag(const T *__restrict__ W, int
   double s[EPV];
 #pragma unroll
   for (int e = 0; e < EPV; ++e) s[e] = 0.0;
-  for (int64_t l = col0 + rg; l < n_pad; l += NRG) {
-    const vec_t v = *reinterpret_cast<const vec_t *>(Wl + l * ldw);
+  for (int64_t l = col0 + rg; l < n_pad; l += 4 * NRG) {         // four rows in flight per thread, as k_wt_matvec (same summation order)
+    vec_t v[4];
 #pragma unroll
-    for (int e = 0; e < EPV; ++e) s[e] += (double)v[e] * (double)v[e];
+    for (int u = 0; u < 4; ++u) {
+      const int64_t ll = l + u * NRG;
+      v[u] = *reinterpret_cast<const vec_t *>(Wl + (ll < n_pad ? ll : n_pad - 1) * ldw);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (l + u * NRG < n_pad) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) s[e] += (double)v[u][e] * (double)v[u][e];
+      }
   }
 #pragma unroll
   for (int e = 0; e < EPV; ++e) red[rg][cl + e] = s[e];
