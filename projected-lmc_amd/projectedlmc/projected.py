@@ -368,7 +368,8 @@ class _LateCheck:
 
     def __init__(self, mll, dc, args):
         self.mll, self.dc, self.args = mll, dc, args
-        self.done = False
+        self.stream = torch.cuda.current_stream(args[1].device)       # the redo runs where the forward pass ran (the callback may
+        self.done = False                                             # come from an autograd worker thread with its own current stream)
         self.result = None
         self.snapshot = None
 
@@ -396,7 +397,7 @@ class _LateCheck:
                       "computed from it before backward() keep the failed pass's value", RuntimeWarning)
         for p, g in snapshot:
             p.grad = g
-        with torch.enable_grad():
+        with torch.enable_grad(), torch.cuda.stream(self.stream):
             # the graph behind the prior (the constrained hyper-parameters) went with the backward pass that just ended: build it
             # again -- in training mode the prior is the model at its training inputs
             args = (mll.model(*mll.model.train_inputs),) + tuple(args[1:])
