@@ -146,6 +146,20 @@ int plmc_potrf_ex_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t st
 int plmc_potrf_ex_f64(double *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, double *Vd, double *logdet,
                       int *info, int with_inverse, int q, const double *eig_lo, void *stream);
 
+/* Assembly + factorisation in one call (round 4): plmc_assemble_* followed by plmc_potrf_ex_* on the same buffers, with the
+ * assembly overlapped with the sweep -- the sweep writes the rows of its first group of block rows on the caller's stream and
+ * queues the other rows (and the scan of the diagonal for the fp16 scales, which needs them) on a helper stream beside that
+ * group's chain; nothing reads them before.  The augmented columns must be in place BEFORE the call (plmc_write_rhs_*,
+ * plmc_assemble_cross_*).  n_pad = plmc_pad(n).  Same kernels on the same data as the two separate calls: bit-identical results
+ * (tests/test_gpu_engine.py).  Replaces, like them: `self.covar_module(x)` + `likelihood(dist)` + the Cholesky inside `log_prob`
+ * (projected_lmc.py:316,:1090,:1200-1201). */
+int plmc_factorize_ex_f32(int kind, const float *X, int n, int d, const float *ell, const float *oscale, const float *noise,
+                          float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet, int *info,
+                          int with_inverse, int q, const float *eig_lo, void *stream);
+int plmc_factorize_ex_f64(int kind, const double *X, int n, int d, const double *ell, const double *oscale, const double *noise,
+                          double *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, double *Vd, double *logdet, int *info,
+                          int with_inverse, int q, const double *eig_lo, void *stream);
+
 /*
  * Forward substitution of NEW augmented columns against a buffer that plmc_potrf_* already factorised with
  * with_inverse != 0 (and has not been modified since):  columns [n_pad, n_pad + naug) <- U^-T columns.  wcol0 = first

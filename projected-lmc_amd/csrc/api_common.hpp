@@ -62,6 +62,15 @@ struct Knobs {
 };
 const Knobs &knobs();
 
+// Covariance assembly handed to the sweep (plmc_factorize_ex_*): the sweep queues the rows of its first group on the caller's stream and
+// the rest on a helper stream beside the first group's chain, instead of the caller assembling the whole matrix in front of the sweep
+struct AssembleJob {
+  int kind, n, d;
+  const void *X, *ell, *oscale, *noise;
+};
+// block rows ib0 .. ib0 + nrows - 1 of the covariance matrices (assemble.hip); elem_bytes 4 / 8
+int assemble_rows(const AssembleJob &job, int elem_bytes, void *A, int64_t lda, int64_t strideA, int q, int ib0, int nrows, void *stream);
+
 hipStream_t side_stream(int which = 0);   // per-device helper streams (api.hip), which in {0, 1, 2}; nullptr on failure
 hipEvent_t sync_event(int idx);     // per-device ordering events, idx in [0,16)
 void bind_sweep_ctx(hipStream_t caller, int e_prev_idx);   // select the stream / event set of this caller stream (api.hip)

@@ -922,7 +922,7 @@ __global__ __launch_bounds__(WTMV_NT) void k_w_diag(const T *__restrict__ W, int
 // everywhere).  eig_lo: q lower bounds of the smallest eigenvalue (device), needed by SplitH2 only.
 template <typename T, class S>
 int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *Vd, double *logdet, int *info,
-               int with_inverse_arg, int q, const float *eig_lo, void *stream) {
+               int with_inverse_arg, int q, const float *eig_lo, void *stream, const AssembleJob *job = nullptr) {
   constexpr bool bf3 = !std::is_void<S>::value;
   // with_inverse & 4 (split engine, with the inverse factor): KEEP the planes of the solved rows of every group instead of
   // rolling over two buffers -- Vd then has plmc_vd_blocks_keep blocks per latent -- so that plmc_potrs_aug_kept_* can later run
@@ -1132,12 +1132,17 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // tiles of the diagonal-block outputs that k_diag leaves alone (they are read as parts of full 128 x 128 operands)
   hipLaunchKernelGGL(k_zero_diag_out<T>, dim3(m > GMAX ? m : GMAX, q), dim3(NTHREADS), 0, st, Vd, strideV, m, Wg, (int64_t)LDG,
                      strideV, (int64_t)NB * LDG + NB, GMAX, (int64_t)GMAX * NB);    // (+ the chain kernel's counters in the pad column of Wg)
-  if constexpr (bf3)                                      // scales of the operand families (SplitB3: ones), before anything splits
-  {
-    if (SS::NPL == 2)
-      hipLaunchKernelGGL(k_scale_scan, dim3(SCAN_PARTS, q), dim3(NTHREADS), 0, st, (const float *)A, n_pad, lda, strideA, (int)naug_pad, scl, sc_lat);
-    hipLaunchKernelGGL((k_split_scales<SS>), dim3(q), dim3(64), 0, st, n_pad, eig_lo, scl, sc_lat);
-  }
+  auto scales = [&](hipStream_t s) {                      // scales of the operand families (SplitB3: ones), before anything splits
+    if constexpr (bf3) {
+      if (SS::NPL == 2)
+        hipLaunchKernelGGL(k_scale_scan, dim3(SCAN_PARTS, q), dim3(NTHREADS), 0, s, (const float *)A, n_pad, lda, strideA, (int)naug_pad, scl, sc_lat);
+      hipLaunchKernelGGL((k_split_scales<SS>), dim3(q), dim3(64), 0, s, n_pad, eig_lo, scl, sc_lat);
+    }
+  };
+  // A sweep that also assembles (plmc_factorize_ex_*, `job`) with the look-ahead on: only the rows of the first group are written in
+  // front of the chain, the others -- and the scan of the diagonal for the scales, which needs them -- ride on the helper stream H
+  // beside the first group's chain (the first consumer of either, the transpose + head panel of group 0, waits for them: e_sc).
+  // `fused_la` is settled below, once the look-ahead is known to run.
   auto finish = [&]() {
     hipLaunchKernelGGL(k_logdet<T>, dim3(q), dim3(NTHREADS), 0, st, (const T *)A, n_pad, lda, strideA, logdet, info,
                        (const T *)(Wg + (int64_t)LDG + (int64_t)GMAX * NB), strideV, q);    // (the chain kernel's abort words: one per launch, at its first latent)
@@ -1262,7 +1267,14 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   hipStream_t K = (serial || !kacc_on || !bf3) ? nullptr : side_stream(2);
   hipEvent_t e_doneK = sync_event(11);
   if (!e_doneK) K = nullptr;
+  hipEvent_t e_sc = sync_event(12);
   const bool la = C && H && e_entry && e_v && e_gh && e_p && e_hd && e_tail && e_doneC && e_doneH && e_prev && ng > 2;
+  const bool fused_la = la && job && e_sc;
+  if (job && !fused_la) {                                // no overlap to be had: the whole matrix first, as the separate call would
+    const int rc = assemble_rows(*job, (int)sizeof(T), A, lda, strideA, q, 0, m, st);
+    if (rc != 0) return rc;
+  }
+  if (!fused_la) scales(st);
   if (!la) {
     // one stream: chain -> transpose -> group panel over every column -> trailing update of every row below
     // split engine: which engine a tile goes through must not depend on the schedule -- the same launches as under the look-ahead
@@ -1303,15 +1315,26 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // gpanel_rest(gi) read: by then C has waited for e_hd(gi), recorded behind it.  U1 / head / tail touch disjoint
   // tiles; every tile receives its updates in the same order as on one stream, so the result is bit-identical to the
   // serial schedule (tests/test_gpu_edges.py).
+  if (fused_la) {                                                               // rows of the first group
+    const int rc = assemble_rows(*job, (int)sizeof(T), A, lda, strideA, q, 0, G0(1), st);
+    if (rc != 0) return rc;
+  }
   (void)hipEventRecord(e_entry, st);
   (void)hipStreamWaitEvent(C, e_entry, 0);
   (void)hipStreamWaitEvent(H, e_entry, 0);
+  if (fused_la) {
+    const int rc = assemble_rows(*job, (int)sizeof(T), A, lda, strideA, q, G0(1), m - G0(1), H);            // the other rows, beside chain(0)
+    if (rc != 0) return rc;
+    scales(H);
+    (void)hipEventRecord(e_sc, H);
+  }
   raw_planes0(H, G0(1));                                                        // (the head panel of the first group waits for it: e_hd)
   (void)hipEventRecord(e_hd, H);
   for (int gi = 0; gi < ng; ++gi) {
     const int g0 = G0(gi), g1 = G0(gi + 1), g2 = G0(gi + 2), G = g1 - g0;
     const T *Vg = Vg2[gi & 1];
     chain(gi, C);
+    if (fused_la && gi == 0) (void)hipStreamWaitEvent(C, e_sc, 0);             // rows below the first group and the scales (planes of V, head panel)
     vtrans(gi, C);
     (void)hipEventRecord(e_v, C);
     if (gi > 0 || bf3) (void)hipStreamWaitEvent(C, e_hd, 0);                   // head(gi - 1): rows R0 final (split engine: and their raw planes)
@@ -1547,12 +1570,30 @@ int64_t plmc_vd_blocks_keep(int64_t n_pad, int64_t lda) {
 // PLMC_SPLIT picks the arithmetic of the bulk fp32 products: 0 = fp32 MFMA everywhere, 3 = SplitB3, 2 (default) = SplitH2
 // where the caller supplies eigenvalue bounds (plmc_potrf_ex_f32), SplitB3 otherwise.
 static int potrf_f32_any(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet, int *info,
-                         int with_inverse, int q, const float *eig_lo, void *stream) {
+                         int with_inverse, int q, const float *eig_lo, void *stream, const plmc::AssembleJob *job = nullptr) {
   const int split = plmc::knobs().split;
-  if (split == 0) return plmc::potrf_impl<float, void>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, nullptr, stream);
+  if (split == 0) return plmc::potrf_impl<float, void>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, nullptr, stream, job);
   if (split == 2 && eig_lo)
-    return plmc::potrf_impl<float, plmc::SplitH2>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, eig_lo, stream);
-  return plmc::potrf_impl<float, plmc::SplitB3>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, nullptr, stream);
+    return plmc::potrf_impl<float, plmc::SplitH2>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, eig_lo, stream, job);
+  return plmc::potrf_impl<float, plmc::SplitB3>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, nullptr, stream, job);
+}
+// plmc_assemble_* + plmc_potrf_ex_* in one call (the augmented columns are written by the caller BEFORE it: plmc_write_rhs_*,
+// plmc_assemble_cross_*): the sweep writes the rows of its first group of block rows itself and queues the others beside that
+// group's chain.  Same kernels on the same data as the two calls: bit-identical results.
+int plmc_factorize_ex_f32(int kind, const float *X, int n, int d, const float *ell, const float *oscale, const float *noise, float *A,
+                          int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet, int *info, int with_inverse, int q,
+                          const float *eig_lo, void *stream) {
+  PLMC_REQUIRE(n_pad == plmc_pad(n), "n_pad must be plmc_pad(n)");
+  const plmc::AssembleJob job{kind, n, d, X, ell, oscale, noise};
+  return potrf_f32_any(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, eig_lo, stream, &job);
+}
+int plmc_factorize_ex_f64(int kind, const double *X, int n, int d, const double *ell, const double *oscale, const double *noise, double *A,
+                          int64_t n_pad, int64_t lda, int naug, int64_t strideA, double *Vd, double *logdet, int *info, int with_inverse, int q,
+                          const double *eig_lo, void *stream) {
+  (void)eig_lo;
+  PLMC_REQUIRE(n_pad == plmc_pad(n), "n_pad must be plmc_pad(n)");
+  const plmc::AssembleJob job{kind, n, d, X, ell, oscale, noise};
+  return plmc::potrf_impl<double, void>(A, n_pad, lda, naug, strideA, Vd, logdet, info, with_inverse, q, nullptr, stream, &job);
 }
 int plmc_potrf_f32(float *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, float *Vd, double *logdet,
                    int *info, int with_inverse, int q, void *stream) {

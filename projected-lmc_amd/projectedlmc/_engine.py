@@ -131,8 +131,12 @@ def factorize(kind, X, ell, oscale, noise, rhs, ws, Xs=None, kacc=False):
     st = _hip.stream_ptr(dev)
     k = _hip.KIND[kind]
     q, n, d = ws.q, ws.n, X.shape[1]
-    L.call("plmc_assemble", dt, k, _hip.ptr(X), n, d, _hip.ptr(ell), _hip.ptr(oscale), _hip.ptr(noise),
-           _hip.ptr(ws.A), ws.lda, ws.strideA, q, st)
+    # round 4: assembly and sweep as ONE library call (plmc_factorize_ex_*): the sweep writes the rows of its first group itself and
+    # queues the others beside that group's chain (same kernels, same data: bit-identical; PLMC_FUSED_ASSEMBLE=0: two calls)
+    fused = os.environ.get("PLMC_FUSED_ASSEMBLE", "1") != "0"
+    if not fused:
+        L.call("plmc_assemble", dt, k, _hip.ptr(X), n, d, _hip.ptr(ell), _hip.ptr(oscale), _hip.ptr(noise),
+               _hip.ptr(ws.A), ws.lda, ws.strideA, q, st)
     nrhs = 0 if rhs is None else rhs.shape[1]
     if ws.naug_pad > 0:
         L.call("plmc_write_rhs", dt, _hip.ptr(rhs), nrhs, n, _hip.ptr(ws.A), ws.lda, ws.strideA, 0, ws.naug_pad, q, st)
@@ -141,9 +145,13 @@ def factorize(kind, X, ell, oscale, noise, rhs, ws, Xs=None, kacc=False):
                _hip.ptr(oscale), _hip.ptr(ws.A), ws.lda, ws.strideA, ws.n_pad + nrhs, ws.n_pad, q, st)
     # eig_lo = the noise variances: lambda_min(K + s2 I) >= s2 -- the bound the two-plane fp16 split of the bulk fp32 products
     # scales its operands with (include/plmc.h, plmc_potrf_ex_*); ignored by the fp64 entry point
-    L.call("plmc_potrf_ex", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.naug, ws.strideA, _hip.ptr(ws.Vd),
-           _hip.ptr(ws.logdet), _hip.ptr(ws.info), ((2 if kacc else 1) | (4 if ws.keep_planes else 0)) if ws.with_inverse else 0, q,
-           _hip.ptr(noise), st)
+    flags = ((2 if kacc else 1) | (4 if ws.keep_planes else 0)) if ws.with_inverse else 0
+    if fused:
+        L.call("plmc_factorize_ex", dt, k, _hip.ptr(X), n, d, _hip.ptr(ell), _hip.ptr(oscale), _hip.ptr(noise), _hip.ptr(ws.A), ws.n_pad,
+               ws.lda, ws.naug, ws.strideA, _hip.ptr(ws.Vd), _hip.ptr(ws.logdet), _hip.ptr(ws.info), flags, q, _hip.ptr(noise), st)
+    else:
+        L.call("plmc_potrf_ex", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.naug, ws.strideA, _hip.ptr(ws.Vd),
+               _hip.ptr(ws.logdet), _hip.ptr(ws.info), flags, q, _hip.ptr(noise), st)
 
 
 def sweep_accumulates_kinv():

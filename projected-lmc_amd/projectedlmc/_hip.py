@@ -28,6 +28,7 @@ _TYPED = {
     "plmc_assemble_cross": [_I, _P, _I, _P, _I, _I, _P, _P, _P, _L, _L, _L, _L, _I, _P],
     "plmc_potrf": [_P, _L, _L, _I, _L, _P, _P, _P, _I, _I, _P],
     "plmc_potrf_ex": [_P, _L, _L, _I, _L, _P, _P, _P, _I, _I, _P, _P],
+    "plmc_factorize_ex": [_I, _P, _I, _I, _P, _P, _P, _P, _L, _L, _I, _L, _P, _P, _P, _I, _I, _P, _P],
     "plmc_potrs_aug": [_P, _L, _L, _I, _L, _L, _P, _I, _P],
     "plmc_potrs_aug_kept": [_P, _L, _L, _I, _L, _L, _P, _I, _P, _P],
     "plmc_extract_col": [_P, _L, _L, _L, _I, _P, _P, _I, _P],

@@ -259,6 +259,17 @@ def _schedule_independence_body(eng, n, q, dtype):
         assert ndiff == 0, "%s=%s: %d elements of the factor buffer differ" % (knob, val, ndiff)
         assert torch.equal(ld, ld_ref) and torch.equal(info, info_ref)
         del A
+    # (d) assembly and sweep as one library call (plmc_factorize_ex_*: only the first group's rows are assembled in front of the chain,
+    # the others beside it -- the default of eng.factorize, so every run above was one) against plmc_assemble_* + plmc_potrf_ex_*
+    os.environ["PLMC_FUSED_ASSEMBLE"] = "0"
+    try:
+        A, ld, info = factor()
+    finally:
+        del os.environ["PLMC_FUSED_ASSEMBLE"]
+    ndiff = int((A != ref).sum())
+    assert ndiff == 0, "two calls instead of plmc_factorize_ex: %d elements of the factor buffer differ" % ndiff
+    assert torch.equal(ld, ld_ref) and torch.equal(info, info_ref)
+    del A
     del ref, ws
     torch.cuda.empty_cache()
 
