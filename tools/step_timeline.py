@@ -1,10 +1,10 @@
-"""Dev aid: one whole training step (from one k_assemble to the next) out of a rocprofv3 kernel-trace CSV: what runs outside the
+"""Dev aid: one whole training step (from one k_write_rhs to the next) out of a rocprofv3 kernel-trace CSV: what runs outside the
 library's kernels (torch: projection, loss terms, optimiser), where, and how long the GPU idles between kernels.
     python tools/step_timeline.py <kernel_trace.csv> [verbose]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-asm = [i for i, r in enumerate(rows) if "k_assemble" in r["Kernel_Name"]]
+asm = [i for i, r in enumerate(rows) if "k_write_rhs" in r["Kernel_Name"]]      # one per training step, in front of the factorisation
 a, b = asm[-2], asm[-1]
 win = rows[a:b]
 t0 = int(win[0]["Start_Timestamp"])
