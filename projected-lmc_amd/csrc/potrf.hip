@@ -1143,8 +1143,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // front of the chain, the others -- and the scan of the diagonal for the scales, which needs them -- ride on the helper stream H
   // beside the first group's chain (the first consumer of either, the transpose + head panel of group 0, waits for them: e_sc).
   // `fused_la` is settled below, once the look-ahead is known to run.
-  auto finish = [&]() {
-    hipLaunchKernelGGL(k_logdet<T>, dim3(q), dim3(NTHREADS), 0, st, (const T *)A, n_pad, lda, strideA, logdet, info,
+  auto finish = [&](hipStream_t s) {
+    hipLaunchKernelGGL(k_logdet<T>, dim3(q), dim3(NTHREADS), 0, s, (const T *)A, n_pad, lda, strideA, logdet, info,
                        (const T *)(Wg + (int64_t)LDG + (int64_t)GMAX * NB), strideV, q);    // (the chain kernel's abort words: one per launch, at its first latent)
     return launch_status("potrf_impl");
   };
@@ -1301,7 +1301,7 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       }
       kacc(gi, st);
     }
-    return finish();
+    return finish(st);
   }
   // Look-ahead on three streams.  With R0 = the rows of group gi, R1 = the next group, R2 = the one after:
   //   C (helper, high priority; latency-bound): chain(gi) -> vtrans(gi) -> [e_v] -> (wait e_hd(gi-1)) gpanel_head(gi):
@@ -1366,13 +1366,16 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
     (void)hipEventRecord(e_doneK, K);
     (void)hipStreamWaitEvent(st, e_doneK, 0);
   }
+  // log det and the pivot / abort check read the diagonal of U and the chain kernels' control words: final behind the last chain,
+  // so they ride on the chain stream beside the last group's panel instead of behind the whole sweep (25 us + a launch gap)
+  const int rc_fin = finish(C);
   (void)hipEventRecord(e_doneC, C);
   (void)hipEventRecord(e_doneH, H);
   (void)hipStreamWaitEvent(st, e_doneC, 0);
   (void)hipStreamWaitEvent(st, e_doneH, 0);
   (void)hipEventRecord(e_prev, st);                      // everything of this sweep is behind this point of the caller's stream
 
-  return finish();
+  return rc_fin;
 }
 
 // Where a sweep of the split engine left the full-height planes of W and the scale of that operand family inside its `Vd`
