@@ -68,8 +68,10 @@ struct AssembleJob {
   int kind, n, d;
   const void *X, *ell, *oscale, *noise;
 };
-// block rows ib0 .. ib0 + nrows - 1 of the covariance matrices (assemble.hip); elem_bytes 4 / 8
-int assemble_rows(const AssembleJob &job, int elem_bytes, void *A, int64_t lda, int64_t strideA, int q, int ib0, int nrows, void *stream);
+// block rows ib0 .. ib0 + nrows - 1 of the covariance matrices (assemble.hip), the first ncols block columns (< 0: all) without the
+// leading skip x skip block triangle; elem_bytes 4 / 8
+int assemble_rows(const AssembleJob &job, int elem_bytes, void *A, int64_t lda, int64_t strideA, int q, int ib0, int nrows, void *stream,
+                  int ncols = -1, int skip = 0);
 
 hipStream_t side_stream(int which = 0);   // per-device helper streams (api.hip), which in {0, 1, 2}; nullptr on failure
 hipEvent_t sync_event(int idx);     // per-device ordering events, idx in [0,16)

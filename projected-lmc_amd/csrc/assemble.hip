@@ -16,9 +16,9 @@ template <typename T>
 __global__ __launch_bounds__(NTHREADS) void k_assemble(int kind, const T *__restrict__ X, int n, int d,
                                                         const T *__restrict__ ell, const T *__restrict__ oscale,
                                                         const T *__restrict__ noise, T *__restrict__ A,
-                                                        int64_t lda, int64_t strideA, int ib0) {
+                                                        int64_t lda, int64_t strideA, int ib0, int skip) {
   const int jb = blockIdx.x, ib = ib0 + blockIdx.y, lat = blockIdx.z;
-  if (jb < ib) return;
+  if (jb < ib || (ib < skip && jb < skip)) return;                 // `skip`: the leading skip x skip block triangle was written by another launch
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T *ui = reinterpret_cast<T *>(smem_raw);
   const int ldu = d + 1;
@@ -137,9 +137,9 @@ template <typename T, int DCAP>
 __global__ __launch_bounds__(NTHREADS) void k_assemble_small(int kind, const T *__restrict__ X, int n, int d,
                                                               const T *__restrict__ ell, const T *__restrict__ oscale,
                                                               const T *__restrict__ noise, T *__restrict__ A,
-                                                              int64_t lda, int64_t strideA, int ib0) {
+                                                              int64_t lda, int64_t strideA, int ib0, int skip) {
   const int jb = blockIdx.x, ib = ib0 + blockIdx.y, lat = blockIdx.z;
-  if (jb < ib) return;
+  if (jb < ib || (ib < skip && jb < skip)) return;
   constexpr int ldu = DCAP + 1;
   __shared__ T ui[NB * ldu], uj[NB * ldu];
   const int tid = threadIdx.x;
@@ -223,10 +223,11 @@ __global__ __launch_bounds__(NTHREADS) void k_assemble_cross(int kind, const T *
   }
 }
 
-// block rows ib0 .. ib0 + nrows - 1 (nrows < 0: all of them); the tiles right of the diagonal of those rows
+// block rows ib0 .. ib0 + nrows - 1 (nrows < 0: all of them); the tiles right of the diagonal of those rows, the first `ncols` block
+// columns only (ncols < 0: all), without the leading skip x skip block triangle
 template <typename T>
 int assemble_impl(int kind, const T *X, int n, int d, const T *ell, const T *oscale, const T *noise, T *A,
-                  int64_t lda, int64_t strideA, int q, void *stream, int ib0 = 0, int nrows = -1) {
+                  int64_t lda, int64_t strideA, int q, void *stream, int ib0 = 0, int nrows = -1, int ncols = -1, int skip = 0) {
   PLMC_REQUIRE(kind >= 0 && kind <= 4, "unknown kernel kind");
   PLMC_REQUIRE(X && ell && noise && A, "null pointer");
   PLMC_REQUIRE(n > 0 && q > 0 && d > 0 && d <= MAX_DIM, "need n>0, q>0, 0<d<=plmc_max_dim()");
@@ -235,20 +236,21 @@ int assemble_impl(int kind, const T *X, int n, int d, const T *ell, const T *osc
   PLMC_REQUIRE(strideA >= n_pad * lda || q == 1, "strideA too small");
   const int m = (int)(n_pad / NB);
   if (nrows < 0) nrows = m - ib0;
-  PLMC_REQUIRE(ib0 >= 0 && nrows >= 0 && ib0 + nrows <= m, "row range outside the matrix");
-  if (nrows == 0) return 0;
+  if (ncols < 0) ncols = m;
+  PLMC_REQUIRE(ib0 >= 0 && nrows >= 0 && ib0 + nrows <= m && ncols <= m && skip >= 0, "row / column range outside the matrix");
+  if (nrows == 0 || ncols == 0) return 0;
   size_t smem = 2 * NB * (d + 1) * sizeof(T);
   const double tiles = (double)nrows * (m - ib0) - (double)nrows * (nrows - 1) / 2.0;   // upper tiles of these rows
   ProfScope ps(PK_ASSEMBLE, (hipStream_t)stream, 0.0, q * tiles * NB * NB * sizeof(T));
   if (d <= 4 && kind != K_SPLINE)              // the spline kernel is evaluated by the general kernel (not a function of r2)
-    hipLaunchKernelGGL((k_assemble_small<T, 4>), dim3(m, nrows, q), dim3(NTHREADS), 0, (hipStream_t)stream, kind, X, n, d,
-                       ell, oscale, noise, A, lda, strideA, ib0);
+    hipLaunchKernelGGL((k_assemble_small<T, 4>), dim3(ncols, nrows, q), dim3(NTHREADS), 0, (hipStream_t)stream, kind, X, n, d,
+                       ell, oscale, noise, A, lda, strideA, ib0, skip);
   else if (d <= 8 && kind != K_SPLINE)
-    hipLaunchKernelGGL((k_assemble_small<T, 8>), dim3(m, nrows, q), dim3(NTHREADS), 0, (hipStream_t)stream, kind, X, n, d,
-                       ell, oscale, noise, A, lda, strideA, ib0);
+    hipLaunchKernelGGL((k_assemble_small<T, 8>), dim3(ncols, nrows, q), dim3(NTHREADS), 0, (hipStream_t)stream, kind, X, n, d,
+                       ell, oscale, noise, A, lda, strideA, ib0, skip);
   else
-    hipLaunchKernelGGL(k_assemble<T>, dim3(m, nrows, q), dim3(NTHREADS), smem, (hipStream_t)stream, kind, X, n, d, ell,
-                       oscale, noise, A, lda, strideA, ib0);
+    hipLaunchKernelGGL(k_assemble<T>, dim3(ncols, nrows, q), dim3(NTHREADS), smem, (hipStream_t)stream, kind, X, n, d, ell,
+                       oscale, noise, A, lda, strideA, ib0, skip);
   return launch_status(__func__);
 }
 
@@ -288,12 +290,13 @@ int assemble_cross_impl(int kind, const T *X, int n, const T *Xs, int ns, int d,
   return launch_status(__func__);
 }
 
-int assemble_rows(const AssembleJob &job, int elem_bytes, void *A, int64_t lda, int64_t strideA, int q, int ib0, int nrows, void *stream) {
+int assemble_rows(const AssembleJob &job, int elem_bytes, void *A, int64_t lda, int64_t strideA, int q, int ib0, int nrows, void *stream,
+                  int ncols, int skip) {
   if (elem_bytes == 4)
     return assemble_impl<float>(job.kind, (const float *)job.X, job.n, job.d, (const float *)job.ell, (const float *)job.oscale, (const float *)job.noise,
-                                (float *)A, lda, strideA, q, stream, ib0, nrows);
+                                (float *)A, lda, strideA, q, stream, ib0, nrows, ncols, skip);
   return assemble_impl<double>(job.kind, (const double *)job.X, job.n, job.d, (const double *)job.ell, (const double *)job.oscale,
-                               (const double *)job.noise, (double *)A, lda, strideA, q, stream, ib0, nrows);
+                               (const double *)job.noise, (double *)A, lda, strideA, q, stream, ib0, nrows, ncols, skip);
 }
 }  // namespace plmc
 

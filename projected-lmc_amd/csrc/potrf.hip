@@ -1139,8 +1139,8 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
       hipLaunchKernelGGL((k_split_scales<SS>), dim3(q), dim3(64), 0, s, n_pad, eig_lo, scl, sc_lat);
     }
   };
-  // A sweep that also assembles (plmc_factorize_ex_*, `job`) with the look-ahead on: only the rows of the first group are written in
-  // front of the chain, the others -- and the scan of the diagonal for the scales, which needs them -- ride on the helper stream H
+  // A sweep that also assembles (plmc_factorize_ex_*, `job`) with the look-ahead on: only the first group's own block triangle is written
+  // in front of the chain, everything else -- and the scan of the diagonal for the scales, which needs it -- rides on the helper stream H
   // beside the first group's chain (the first consumer of either, the transpose + head panel of group 0, waits for them: e_sc).
   // `fused_la` is settled below, once the look-ahead is known to run.
   auto finish = [&](hipStream_t s) {
@@ -1315,15 +1315,15 @@ int potrf_impl(T *A, int64_t n_pad, int64_t lda, int naug, int64_t strideA, T *V
   // gpanel_rest(gi) read: by then C has waited for e_hd(gi), recorded behind it.  U1 / head / tail touch disjoint
   // tiles; every tile receives its updates in the same order as on one stream, so the result is bit-identical to the
   // serial schedule (tests/test_gpu_edges.py).
-  if (fused_la) {                                                               // rows of the first group
-    const int rc = assemble_rows(*job, (int)sizeof(T), A, lda, strideA, q, 0, G0(1), st);
+  if (fused_la) {                                                               // the first group's own triangle: all its chain reads
+    const int rc = assemble_rows(*job, (int)sizeof(T), A, lda, strideA, q, 0, G0(1), st, G0(1));
     if (rc != 0) return rc;
   }
   (void)hipEventRecord(e_entry, st);
   (void)hipStreamWaitEvent(C, e_entry, 0);
   (void)hipStreamWaitEvent(H, e_entry, 0);
   if (fused_la) {
-    const int rc = assemble_rows(*job, (int)sizeof(T), A, lda, strideA, q, G0(1), m - G0(1), H);            // the other rows, beside chain(0)
+    const int rc = assemble_rows(*job, (int)sizeof(T), A, lda, strideA, q, 0, m, H, -1, G0(1));            // everything else, beside chain(0)
     if (rc != 0) return rc;
     scales(H);
     (void)hipEventRecord(e_sc, H);

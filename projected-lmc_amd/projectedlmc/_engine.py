@@ -283,7 +283,6 @@ class ExactLatentLogProb(torch.autograd.Function):
             info = _DeferredInfo(ws) if check else None
             L.call("plmc_extract_col", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, 0, _hip.ptr(ws.z),
                    _hip.ptr(ws.quad), q, st)
-            lp = -0.5 * (ws.quad + ws.logdet + n * LOG2PI)
             if need_grad:
                 L.call("plmc_wt_matvec", dt, _hip.ptr(ws.W), ws.n_pad, ws.ldw, ws.strideW, _hip.ptr(ws.z),
                        _hip.ptr(ws.alpha), q, st)
@@ -306,6 +305,9 @@ class ExactLatentLogProb(torch.autograd.Function):
                 if gs is not None:
                     ws.pending = torch.cuda.Event()
                     ws.pending.record(gs)
+            # (the three small kernels of this line are queued BEHIND the gradient kernel's launch: in front of plmc_wt_matvec they
+            # sat on the serial path sweep -> alpha -> gradient kernel)
+            lp = -0.5 * (ws.quad + ws.logdet + n * LOG2PI)
             return lp, info
 
         # jitter ladder of gpytorch's psd_safe_cholesky [gpytorch-knowledge] (see factorize_checked)
