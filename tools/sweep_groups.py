@@ -2,7 +2,7 @@
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "plmc" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-last = max(i for i, r in enumerate(rows) if "k_assemble" in r["Kernel_Name"])
+last = max(i for i, r in enumerate(rows) if "k_zero_diag_out" in r["Kernel_Name"])
 rows = rows[last:]
 t0 = int(rows[0]["Start_Timestamp"])
 nm = lambda r: r["Kernel_Name"].split("<")[0].replace("void plmc::", "")

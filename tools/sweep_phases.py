@@ -4,10 +4,10 @@ the caller's stream.  Times in us from the start of the sweep: start-end (durati
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "plmc" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-last = max(i for i, r in enumerate(rows) if "k_assemble" in r["Kernel_Name"])
+last = max(i for i, r in enumerate(rows) if "k_zero_diag_out" in r["Kernel_Name"])      # first kernel of a sweep
 rows = rows[last:]
-end = next((i for i, r in enumerate(rows) if "k_logdet" in r["Kernel_Name"]), len(rows))
-rows = rows[:end + 1]
+end = next((i for i, r in enumerate(rows) if "k_extract_col" in r["Kernel_Name"]), len(rows))   # first kernel behind it (k_logdet rides on the chain stream)
+rows = rows[:end]
 t0 = int(rows[0]["Start_Timestamp"])
 nm = lambda r: r["Kernel_Name"].split("(")[0].replace("void plmc::", "")
 ev = [(nm(r), (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3, r.get("Queue_Id", "?")) for r in rows]

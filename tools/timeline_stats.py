@@ -2,10 +2,10 @@
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "plmc" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-last = max(i for i, r in enumerate(rows) if "k_assemble" in r["Kernel_Name"])
+last = max(i for i, r in enumerate(rows) if "k_zero_diag_out" in r["Kernel_Name"])      # first kernel of a sweep
 rows = rows[last:]
-end = next((i for i, r in enumerate(rows) if "k_logdet" in r["Kernel_Name"]), len(rows))
-rows = rows[:end + 1]
+end = next((i for i, r in enumerate(rows) if "k_extract_col" in r["Kernel_Name"]), len(rows))   # first kernel behind it (k_logdet rides on the chain stream)
+rows = rows[:end]
 t0 = int(rows[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in rows)
 name = lambda r: r["Kernel_Name"].split("(")[0].replace("void plmc::", "")
 byq, byk = {}, {}

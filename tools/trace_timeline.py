@@ -4,8 +4,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 name = lambda r: r["Kernel_Name"].split("<")[0].replace("void plmc::", "")
 rows = [r for r in rows if "plmc" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# last sweep = after the last k_assemble
-last = max(i for i, r in enumerate(rows) if "k_assemble" in r["Kernel_Name"])
+# last sweep = from the last k_zero_diag_out (its first kernel)
+last = max(i for i, r in enumerate(rows) if "k_zero_diag_out" in r["Kernel_Name"])
 rows = rows[last:]
 t0 = int(rows[0]["Start_Timestamp"])
 lo, hi = int(sys.argv[2]), int(sys.argv[3])
