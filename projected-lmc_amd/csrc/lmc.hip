@@ -135,11 +135,13 @@ __global__ __launch_bounds__(NTHREADS, TILE_MIN_WAVES<T>) void k_lmc_kinv_grad(i
                                                              int n, int d, int p, int q, const T *__restrict__ ell,
                                                              const T *__restrict__ oscale, const T *__restrict__ B,
                                                              double *__restrict__ partials) {
-  const int jb = blockIdx.x, ib = blockIdx.y;
-  if (jb < ib) return;
+  // XCD-dealt 8 x 8 super-tiles (gemm_core.hpp, the order of k_kinv_grad): the tiles of a super-tile stream their strips of W through
+  // one L2 (round 4; a plain (jb, ib) grid before)
+  const int m = (int)(N_pad / NB);
+  int lat_, ib, jb;
+  if (!xcd_tri_decode(blockIdx.x, m, 1, lat_, ib, jb)) return;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T *smem = reinterpret_cast<T *>(smem_raw);
-  const int m = (int)(N_pad / NB);
   const T *Wl = W + (int64_t)jb * NB * ldw;
   Acc<T> acc;
   acc.zero();
@@ -334,7 +336,7 @@ int lmc_kinv_grad_impl(int kind, const T *W, int64_t N_pad, int64_t ldw, const T
   do {                                                                                                                   \
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lmc_kinv_grad<T, DC>),                                    \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                                     \
-    hipLaunchKernelGGL((k_lmc_kinv_grad<T, DC>), dim3(m, m), dim3(NTHREADS), smem, st, kind, W, N_pad, ldw, alpha, X, n,  \
+    hipLaunchKernelGGL((k_lmc_kinv_grad<T, DC>), dim3(xcd_tri_grid(m, 1)), dim3(NTHREADS), smem, st, kind, W, N_pad, ldw, alpha, X, n,  \
                        d, p, q, ell, oscale, B, part);                                                                    \
   } while (0)
     if (d <= 8) PLMC_LAUNCH_LKG(8);
