@@ -280,6 +280,8 @@ class ExactLatentLogProb(torch.autograd.Function):
         def enqueue(noise_eff):
             """factorisation + everything that consumes it; returns (logp, deferred pivot check)."""
             factorize(kind, Xc, ellc, osc, noise_eff, yc.reshape(q, 1, n), ws, kacc=kacc)
+            # (the copy of `info` stays right behind the sweep: the late pivot check of a training step waits for it, and with one
+            # latent per rank the host, which then still has the optimiser step and the next projection to queue, is nearly critical)
             info = _DeferredInfo(ws) if check else None
             L.call("plmc_extract_col", dt, _hip.ptr(ws.A), ws.n_pad, ws.lda, ws.strideA, 0, _hip.ptr(ws.z),
                    _hip.ptr(ws.quad), q, st)
